@@ -1,0 +1,193 @@
+"""The CPU restatement (oracle/) against the fixtures minted from the reference itself
+(oracle/gen_golden.py).  This is what pins the oracle; the GPU parity tests then compare the HIP
+path with the oracle.  Tolerances: fp32 CPU vs fp32 CPU, 5e-5 absolute on O(1) tensors."""
+import numpy as np
+import pytest
+import torch
+
+from clip_decontamination_amd import weights as Wt
+from oracle import vit as OV, refine as OR, jbu as OJ, segment as OS
+
+TOL = 5e-5
+POTSDAM_QIDX = [0, 0, 1, 2, 3, 4, 5, 5]
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdiff(a, b):
+    return (torch.as_tensor(a).float() - torch.as_tensor(b).float()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = Wt.vit_config("tiny-8")
+    return cfg, OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+
+
+@pytest.mark.parametrize("mt", ["vanilla", "MaskCLIP", "ClearCLIP", "SCLIP", "SegEarth", "SFP", "Experimental",
+                                "NACLIP", "NOnly", "GAV"])
+def test_model_types(golden, tiny, mt):
+    cfg, w = tiny
+    g = golden("vit_tiny-8")
+    img = t(g["img"])
+    if mt == "NOnly":
+        img = img[:1]
+    with torch.no_grad():
+        cls, tok = OV.vit_forward(w, cfg, img, mt, True)
+    assert maxdiff(tok, g[f"{mt}.tokens"]) < TOL
+    assert maxdiff(cls, g[f"{mt}.cls"]) < TOL
+
+
+def test_residual_and_native_grid(golden, tiny):
+    cfg, w = tiny
+    g = golden("vit_tiny-8")
+    with torch.no_grad():
+        cls, tok = OV.vit_forward(w, cfg, t(g["img"]), "SegEarth", False)
+        assert maxdiff(tok, g["SegEarth.res.tokens"]) < TOL
+        cls, tok = OV.vit_forward(w, cfg, t(g["img_native"]), "SegEarth", True)
+        assert maxdiff(tok, g["native.tokens"]) < TOL and maxdiff(cls, g["native.cls"]) < TOL
+
+
+SIM = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
+OUT = dict(top_k=5)
+SA = dict(enhancement_strength=0.1, min_self_attn_threshold=0.15, mode="feature", top_k=4)
+COMBOS = {"sim": (SIM, None, None), "out": (None, OUT, None), "sim_out": (SIM, OUT, None), "all": (SIM, OUT, SA),
+          "sa_only": (None, None, SA),
+          "sim2": (dict(similarity_weight=0.5, temperature=2.0, add_self_similarity=False), None, None)}
+
+
+@pytest.mark.parametrize("tag", list(COMBOS))
+@pytest.mark.parametrize("mt", ["SegEarth", "Experimental", "ClearCLIP"])
+def test_refiner_hooks(golden, tiny, tag, mt):
+    cfg, w = tiny
+    g = golden("vit_tiny-8")
+    sc, oc, ac = COMBOS[tag]
+    with torch.no_grad():
+        cls, tok = OV.vit_forward(w, cfg, t(g["img"]), mt, True, similarity_cfg=sc, outlier_cfg=oc, self_attn_cfg=ac)
+    assert maxdiff(tok, g[f"{tag}.{mt}.tokens"]) < TOL
+    assert maxdiff(cls, g[f"{tag}.{mt}.cls"]) < TOL
+
+
+def test_self_attn_enhancer_alone_is_noop(golden):
+    g = golden("vit_tiny-8")     # without an outlier suppressor no attention is captured
+    assert maxdiff(g["sa_only.SegEarth.tokens"], g["SegEarth.tokens"]) == 0.0
+
+
+def test_exact_gelu(golden):
+    cfg = Wt.vit_config("tiny-gelu")
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    g = golden("vit_tiny-gelu")
+    with torch.no_grad():
+        cls, tok = OV.vit_forward(w, cfg, t(g["img"]), "SegEarth", True)
+    assert maxdiff(tok, g["SegEarth.tokens"]) < TOL
+
+
+def test_gem(golden):
+    cfg = Wt.vit_config("tiny-gem")
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    g = golden("vit_tiny-gem")
+    with torch.no_grad():
+        for ign in (True, False):
+            for nm in ("g6", "g4"):
+                tok = OV.gem_forward(w, cfg, t(g[f"{nm}.img"]), ign, 7)
+                assert maxdiff(tok, g[f"{nm}.ign{int(ign)}.tokens"]) < TOL
+
+
+def test_refine_modules(golden):
+    g = golden("refine")
+    grid, attn = t(g["grid"]), t(g["attn"])
+    n = grid.shape[-1] * grid.shape[-2]
+    idx = OR.detect_outliers(attn, n, 8)
+    assert torch.equal(idx, t(g["outlier_idx"]))
+    assert maxdiff(OR.suppress_outliers(grid, idx, 0.1), g["suppressed"]) < 1e-6
+    assert torch.equal(OR.detect_outliers(t(g["attn4"]).mean(1), n, 5), t(g["outlier_idx4"]))
+    for mode in ("feature", "attention"):
+        assert maxdiff(OR.self_attention_enhance(grid, attn, 0.3, 0.05, mode, 6), g[f"selfattn_{mode}"]) < 1e-5
+    f = t(g["sim_feats"])
+    assert maxdiff(OR.similarity_map(f, 1.0, True), g["sim_a"]) < 1e-6
+    assert maxdiff(OR.similarity_map(f, 0.5, False), g["sim_b"]) < 1e-6
+
+
+def test_planted_outliers_in_topk():
+    """Property the reference's own test checks (test_outlier_suppression.py:24-46)."""
+    torch.manual_seed(0)
+    attn = torch.rand(2, 197, 197)
+    attn = attn / attn.sum(-1, keepdim=True)
+    planted = [10, 50, 100]
+    for p in planted:
+        attn[:, 0, p + 1] = 0.5
+        attn[:, p + 1, p + 1] = 0.001
+    idx = OR.detect_outliers(attn, 196, 10)
+    assert idx.shape == (2, 10)
+    for b in range(2):
+        assert set(planted) <= set(idx[b].tolist())
+
+
+@pytest.mark.parametrize("mode", ["weighted", "attention"])
+def test_cross_tile_fusion(golden, mode):
+    g = golden("refine")
+    tiles = t(g["ctf_tiles"])
+    o = OR.CrossTileFusionOracle(mode, 2, 0.3)
+    for hi in range(2):
+        for wi in range(3):
+            r = o(tiles[hi, wi].clone(), hi, wi, 6, 6)
+            assert maxdiff(r, g[f"ctf_{mode}"][hi, wi]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["jbu_one", "jbu_stack"])
+def test_jbu(golden, name):
+    g = golden("jbu")
+    C = g[f"{name}.src"].shape[1]
+    w = OV.to_torch(Wt.make_jbu_weights(name, C, seed=3))
+    with torch.no_grad():
+        out = OJ.jbu_forward(w, t(g[f"{name}.src"]), t(g[f"{name}.guidance"]))
+    assert maxdiff(out, g[f"{name}.out"]) < 1e-4
+    assert maxdiff(OJ.adaptive_conv(t(g["ac_in"]), t(g["ac_filt"])), g["ac_out"]) < 1e-5
+
+
+CASES = {
+    "ex_base": dict(model_type="Experimental", global_debias_factor=0.2, similarity_cfg=SIM, outlier_cfg=dict(top_k=6),
+                    prob_thd=0.1, bg_idx=5, slide_crop=32, slide_stride=16),
+    "ex_pad": dict(model_type="SegEarth", global_debias_factor=0.2, cls_token_lambda=-0.3, slide_crop=36, slide_stride=20),
+    "se_plain": dict(model_type="SegEarth", cls_token_lambda=-0.3, slide_crop=32, slide_stride=16),
+    "ex_small": dict(model_type="ClearCLIP", slide_crop=32, slide_stride=16),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_slide_and_postprocess(golden, tiny, name):
+    cfg, w = tiny
+    g = golden("segment")
+    o = OS.SegOracle(cfg, w, t(g["text"]), torch.tensor(POTSDAM_QIDX), **CASES[name])
+    img = t(g[f"{name}.img"])
+    with torch.no_grad():
+        lg = o.forward_slide(img)
+        assert maxdiff(lg, g[f"{name}.logits"]) < TOL
+        _, pred = o.postprocess(lg[0])
+        assert torch.equal(pred, t(g[f"{name}.pred"]))
+        ff = o.forward_feature(img[:, :, :32, :32], (40, 44))
+        assert maxdiff(ff, g[f"{name}.ff"]) < TOL
+
+
+def test_padsize():
+    assert OS.compute_padsize(512, 512, 14) == (3, 3, 3, 3)
+    assert OS.compute_padsize(224, 224, 16) == (0, 0, 0, 0)
+    assert OS.compute_padsize(36, 37, 8) == (1, 2, 2, 2)
+
+
+def test_real_size_b16_224(golden):
+    """ViT-B/16, one 224x224 tile, 8 queries / 6 classes -- BASELINE.json configs[0]."""
+    g = golden("real_logits")
+    cfg = Wt.vit_config("ViT-B-16")
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    text = torch.from_numpy(Wt.make_text_features(8, cfg.embed_dim))
+    img = torch.from_numpy(Wt.normalize_tiles(Wt.make_tiles_u8(1, 224, seed=1234, smooth=True)))
+    for mt in ("SegEarth", "Experimental"):
+        o = OS.SegOracle(cfg, w, text, torch.tensor(POTSDAM_QIDX), model_type=mt, global_debias_factor=0.2,
+                         similarity_cfg=SIM, outlier_cfg=dict(top_k=30))
+        with torch.no_grad():
+            lg = o.forward_feature(img, (14, 14))[0]
+        assert maxdiff(lg, g[f"ViT-B-16.224.{mt}.logits"]) < 1e-4
+        assert torch.equal(lg.argmax(0).to(torch.uint8), t(g[f"ViT-B-16.224.{mt}.argmax"]))
