@@ -1,0 +1,258 @@
+// Fused multi-term attention for the ViT blocks (throughput mode, bf16 MFMA, f32 softmax).
+// Replaces nn.MultiheadAttention's bmm/softmax/bmm (reference open_clip/transformer.py:204,230-232),
+// the self-self variants of custom_attn (:858-908) and GEM's SelfSelfAttention (gem/gem_utils.py:60-123)
+// without ever materialising an N x N score matrix in HBM.
+//
+// Layout (gfx950, wave64): a workgroup = 4 waves = 128 queries of one (image, head); each wave owns
+// 32 queries.  Scores are computed TRANSPOSED with v_mfma_f32_32x32x16_bf16 (A port = K rows from
+// LDS, B port = Q rows held in registers), so the query sits on the lane and the 32 keys of a
+// sub-block sit in the 16 accumulator registers of the two half-waves: the row max / row sum need
+// 15 local ops + ONE cross-half shuffle.  The probabilities, converted to bf16 in place, are exactly
+// the B operand of the next MFMA (accumulator-as-operand, k order (j&3)+8(j>>2)+4h), which computes
+// O^T = V^T.P^T with V^T fragments fetched by ds_read_b64_tr_b16 (hardware transpose) from a
+// row-major V tile.  O^T keeps the query on the lane, so the online-softmax rescale is lane-local.
+#include "rowops.h"
+
+namespace sg {
+
+constexpr int QB = 128;        // queries per workgroup
+constexpr int KT = 64;         // keys per LDS tile
+
+typedef __attribute__((ext_vector_type(4))) short short4_;
+typedef __attribute__((address_space(3))) short4_* lds_s4_ptr;
+
+template <int DH> struct AttnCfg {
+  static constexpr int KS = DH / 16;                 // k-steps of the score MFMA
+  static constexpr int DVT = (DH + 31) / 32;         // 32-row tiles of O^T
+  static constexpr int K_LD = DH + 8;                // LDS row strides (elements)
+  static constexpr int V_LD = DVT * 32 + 32;
+  static constexpr int CH = DH / 8;                  // 16-byte chunks per row
+};
+
+template <int DH>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t st, int row0, int N, bf16_t* lds, int ld, int tid) {
+  constexpr int CH = DH / 8;
+  for (int idx = tid; idx < KT * CH; idx += 256) {
+    const int r = idx / CH, c = idx % CH;
+    int gr = row0 + r; gr = gr < N ? gr : N - 1;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)gr * st + c * 8);
+    *reinterpret_cast<uint4*>(lds + r * ld + c * 8) = v;
+  }
+}
+
+template <int DH, int TS>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  using C = AttnCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sK = reinterpret_cast<bf16_t*>(smem);                         // [TS][KT][K_LD]
+  bf16_t* sV = sK + TS * KT * C::K_LD;                                  // [KT][V_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q_glob = blockIdx.x * QB + wave * 32 + c;
+  const int q_ld = q_glob < a.N ? q_glob : a.N - 1;
+  const int n = a.N - 1;
+  const float scale = a.scale_per_image ? a.scale_per_image[b] : a.scale;
+  const bool do_pv = a.ctx != nullptr;
+  const int n_streams = a.sum_scores ? 1 : a.n_terms;
+  const int64_t head_off = (int64_t)b * a.sb + (int64_t)hd * DH;
+  const float lse1 = a.resoftmax ? a.lse_in[((int64_t)b * a.H + hd) * a.N + q_ld] : 0.f;
+
+  f32x16 o_tot[C::DVT];
+#pragma unroll
+  for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_tot[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int sidx = 0; sidx < n_streams; ++sidx) {
+    // Q fragments of this stream's terms (B port: lane = query, 8 consecutive k per half-wave)
+    bf16x8 qf[TS][C::KS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      const bf16_t* qp = a.q[a.sum_scores ? t : sidx] + head_off + (int64_t)q_ld * a.st;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + h * 8);
+    }
+    f32x16 o_acc[C::DVT];
+#pragma unroll
+    for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
+    m_run = -INFINITY; l_run = 0.f;
+
+    for (int k0 = 0; k0 < a.N; k0 += KT) {
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < TS; ++t)
+        stage_rows<DH>(a.k[a.sum_scores ? t : sidx] + head_off, a.st, k0, a.N, sK + t * KT * C::K_LD, C::K_LD, tid);
+      if (do_pv) stage_rows<DH>(a.v + (int64_t)b * a.v_sb + (int64_t)hd * DH, a.v_st, k0, a.N, sV, C::V_LD, tid);
+      __syncthreads();
+
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        if (k0 + sub * 32 >= a.N) break;                     // block-uniform
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TS; ++t)
+#pragma unroll
+          for (int ks = 0; ks < C::KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], sacc, 0, 0, 0);   // S^T[key][query]
+          }
+        // scores for query q_glob (lane) and keys key(r) = k0 + 32 sub + (r&3) + 8 (r>>2) + 4 h
+        float sc[16];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = sacc[r] * scale;
+          float bv = 0.f;
+          if (a.bias && key >= 1 && key < a.N && q_ld >= 1) bv = a.bias_w * a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)];
+          if (a.resoftmax) v = __expf(v - lse1) + bv; else v += bv;
+          v = key < a.N ? v : -INFINITY;
+          sc[r] = v;
+          mloc = fmaxf(mloc, v);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = __expf(sc[r] - m_new); lsum += sc[r]; }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (do_pv) {
+#pragma unroll
+          for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+          bf16x8 pf[2];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)sc[8 * s2 + j];
+          // V^T fragments by transposed LDS read: lane 4q+p of a 16-lane group addresses row q, cols 4p..4p+3
+          const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+          for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int key0 = sub * 32 + s2 * 16 + 4 * h;
+              const bf16_t* p0 = sV + (key0 + qq) * C::V_LD + t * 32 + 16 * (g & 1) + 4 * pp;
+              const short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0));
+              const short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0 + 8 * C::V_LD));
+              typedef __attribute__((ext_vector_type(8))) short short8_;
+              short8_ vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              o_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[s2], o_acc[t], 0, 0, 0);
+            }
+        }
+      }
+    }
+    if (do_pv) {
+      const float inv = 1.0f / l_run;
+#pragma unroll
+      for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_tot[t][r] += o_acc[t][r] * inv;
+    }
+  }
+
+  if (a.lse_out && h == 0 && q_glob < a.N) a.lse_out[((int64_t)b * a.H + hd) * a.N + q_glob] = m_run + __logf(l_run);
+  if (do_pv && q_glob < a.N) {
+    bf16_t* op = a.ctx + (int64_t)b * a.ctx_sb + (int64_t)q_glob * a.ctx_st + (int64_t)hd * DH;
+#pragma unroll
+    for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int dv = t * 32 + 8 * g4 + 4 * h;
+        if (dv < DH) {
+          uint2 o;
+          o.x = pack_bf2(o_tot[t][4 * g4 + 0] * a.out_scale, o_tot[t][4 * g4 + 1] * a.out_scale);
+          o.y = pack_bf2(o_tot[t][4 * g4 + 2] * a.out_scale, o_tot[t][4 * g4 + 3] * a.out_scale);
+          *reinterpret_cast<uint2*>(op + dv) = o;
+        }
+      }
+  }
+}
+
+template <int DH, int TS>
+static int launch_attn(const AttnArgs& a, hipStream_t s) {
+  using C = AttnCfg<DH>;
+  const size_t lds = (size_t)(TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
+  auto kern = attn_kernel<DH, TS>;
+  if (lds > 64 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)cdiv(a.N, QB), (unsigned)a.H, (unsigned)a.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+int attention_bf16(const AttnArgs& a, hipStream_t s) {
+  SG_REQUIRE(a.n_terms >= 1 && a.n_terms <= 3, "attention: n_terms=%d", a.n_terms);
+  SG_REQUIRE(a.B > 0 && a.N > 0 && a.H > 0, "attention: empty problem");
+  SG_REQUIRE(a.B < 65536 && a.H < 65536, "attention: grid too large");
+  SG_REQUIRE(a.sb % 8 == 0 && a.st % 8 == 0 && a.v_sb % 8 == 0 && a.v_st % 8 == 0, "attention: strides must be multiples of 8 elements");
+  SG_REQUIRE(!a.resoftmax || a.lse_in, "attention: resoftmax needs lse_in");
+  SG_REQUIRE(a.ctx || a.lse_out, "attention: nothing to compute");
+  const int ts = a.sum_scores ? a.n_terms : 1;
+  SG_REQUIRE(ts <= 2, "attention: at most 2 summed terms");
+#define SG_ATTN_CASE(DHV)                                                   \
+  case DHV: return ts == 2 ? launch_attn<DHV, 2>(a, s) : launch_attn<DHV, 1>(a, s);
+  switch (a.dh) {
+    SG_ATTN_CASE(32)
+    SG_ATTN_CASE(64)
+    SG_ATTN_CASE(80)
+    SG_ATTN_CASE(128)
+    default: return fail(SG_ERR_INVALID, "attention: head_dim %d not built (32, 64, 80, 128)", a.dh);
+  }
+#undef SG_ATTN_CASE
+}
+
+// ---- head-averaged statistics for outlier detection ------------------------------------------------------
+// One wave per token j: for every head, s_cls = scale * q[0].k[j], s_diag = scale * q[j].k[j];
+// probabilities are recovered from the per-row log-sum-exp the attention kernel wrote.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_stats_kernel(const T* __restrict__ qkv, int64_t sb, int64_t st, const float* __restrict__ lse,
+                                                         int N, int H, int dh, float scale, float* __restrict__ attn_cls,
+                                                         float* __restrict__ attn_diag) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  const int D = H * dh;
+  const T* q0 = qkv + (int64_t)b * sb;
+  const T* qj = q0 + (int64_t)j * st;
+  const T* kj = qj + D;
+  float pc = 0.f, pd = 0.f;
+  for (int hd = 0; hd < H; ++hd) {
+    float dc = 0.f, dd = 0.f;
+    for (int d = lane; d < dh; d += 64) {
+      const float kv = to_f32<T>(kj[hd * dh + d]);
+      dc += to_f32<T>(q0[hd * dh + d]) * kv;
+      dd += to_f32<T>(qj[hd * dh + d]) * kv;
+    }
+    dc = wave_sum(dc); dd = wave_sum(dd);
+    const float* l = lse + ((int64_t)b * H + hd) * N;
+    pc += expf(dc * scale - l[0]);
+    pd += expf(dd * scale - l[j]);
+  }
+  if (lane == 0) {
+    attn_cls[(int64_t)b * N + j] = pc / (float)H;
+    attn_diag[(int64_t)b * N + j] = pd / (float)H;
+  }
+}
+
+int attention_stats(const void* qkv, int is_bf16, int64_t sb, int64_t st, const float* lse, int B, int N, int H, int dh,
+                    float scale, float* attn_cls, float* attn_diag, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(N, 4), (unsigned)B);
+  if (is_bf16) hipLaunchKernelGGL(attn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
+  else hipLaunchKernelGGL(attn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+}  // namespace sg

@@ -1,0 +1,622 @@
+// C ABI of libsegearth_hip.so: context / weight packing / the ViT forward orchestration.
+// Everything here is host code issuing asynchronous launches on the caller's stream; the only
+// allocations happen in sg_create (one arena sized from the architecture descriptor).
+#include <string>
+#include <vector>
+#include <math.h>
+#include "rowops.h"
+
+namespace sg {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return code;
+}
+
+// ---- a bump allocator over caller-provided (or arena) memory ------------------------------------------------
+struct Bump {
+  char* base; size_t off, cap; bool dry;
+  Bump(void* p, size_t c, bool d) : base((char*)p), off(0), cap(c), dry(d) {}
+  void* take(size_t bytes) {
+    off = align_up(off, 256);
+    void* p = dry ? nullptr : (void*)(base + off);
+    off += bytes;
+    return p;
+  }
+  template <typename T> T* get(size_t count) { return reinterpret_cast<T*>(take(count * sizeof(T))); }
+};
+
+struct LayerW {
+  void *w_qkv, *w_out, *w_fc, *w_proj;                 // packed [N_out, K] in the compute dtype
+  float *b_qkv, *b_out, *b_fc, *b_proj, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+
+}  // namespace sg
+
+using namespace sg;
+
+struct sg_context {
+  sg_vit_desc d;
+  int device;
+  int Kpatch, Kpad;
+  bool bf16;
+  size_t esz;                                          // bytes per element of the compute dtype
+  void* arena; size_t arena_bytes;
+  std::vector<LayerW> layers;
+  void* w_patch;                                       // [D, Kpad]
+  void* w_projT;                                       // [E, D]
+  float *cls_emb, *pos, *lnpre_g, *lnpre_b, *lnpost_g, *lnpost_b;
+  std::vector<uint8_t> have;                           // which tensors have arrived
+  int n_expected;
+  bool finalized;
+};
+
+namespace sg {
+
+static int expected_tensors(const sg_vit_desc& d) { return 8 + 12 * d.layers; }
+
+// ---- variants of the last-block attention: which (Q,K) terms, summed or not ---------------------------------------
+struct Variant { int n_terms, sum_scores, qsel[3], ksel[3]; float scale_mul; int resoftmax; };   // sel: 0=q 1=k 2=v
+static bool variant_of(int model_type, Variant& v) {
+  switch (model_type) {
+    case SG_VANILLA:      v = {1, 0, {0, 0, 0}, {1, 0, 0}, 1.f, 0}; return true;
+    case SG_CLEARCLIP:    v = {1, 0, {0, 0, 0}, {0, 0, 0}, 1.f, 0}; return true;
+    case SG_SCLIP:        v = {2, 0, {0, 1, 0}, {0, 1, 0}, 1.f, 0}; return true;
+    case SG_SEGEARTH:     v = {3, 0, {0, 1, 2}, {0, 1, 2}, 1.f, 0}; return true;
+    case SG_SFP:          v = {2, 1, {0, 1, 0}, {0, 1, 0}, 0.5f, 0}; return true;
+    case SG_EXPERIMENTAL: v = {2, 1, {1, 0, 0}, {1, 0, 0}, 1.f, 1}; return true;
+    default: return false;
+  }
+}
+
+// Generic multi-term attention in either precision.  Element (b, t, h, d) of a Q/K operand lives at
+// p + b*sb + t*st + h*dh + d (elements of the compute dtype); V has its own strides.
+// f32: materialised scores/probs in `scores`/`probs` ([B*H,N,N] each).  bf16: fused kernel.
+struct AttnBuffers { float* scores; float* probs; float* lse; float* lse1; };
+struct AttnSpec {
+  const void* q[3]; const void* k[3]; int64_t sb, st;
+  const void* v; int64_t v_sb, v_st;
+  int n_terms, sum_scores, resoftmax;
+  float scale; const float* scale_per_image;
+  const float* bias; float bias_w;
+  float out_scale;
+  void* ctx; int64_t ctx_sb, ctx_st;
+  bool want_lse;
+};
+
+static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int dh, const AttnBuffers& buf, hipStream_t s) {
+  if (bf16) {
+    AttnArgs a{};
+    for (int t = 0; t < sp.n_terms; ++t) { a.q[t] = (const bf16_t*)sp.q[t]; a.k[t] = (const bf16_t*)sp.k[t]; }
+    a.v = (const bf16_t*)sp.v; a.sb = sp.sb; a.st = sp.st; a.v_sb = sp.v_sb; a.v_st = sp.v_st;
+    a.n_terms = sp.n_terms; a.sum_scores = sp.sum_scores;
+    a.B = B; a.N = N; a.H = H; a.dh = dh; a.scale = sp.scale; a.scale_per_image = sp.scale_per_image;
+    a.out_scale = sp.out_scale; a.ctx_sb = sp.ctx_sb; a.ctx_st = sp.ctx_st;
+    if (sp.resoftmax) {
+      AttnArgs p = a; p.ctx = nullptr; p.bias = nullptr; p.lse_out = buf.lse1; p.resoftmax = 0;
+      SG_TRY(attention_bf16(p, s));
+      a.resoftmax = 1; a.lse_in = buf.lse1;
+    }
+    a.bias = sp.bias; a.bias_w = sp.bias_w; a.ctx = (bf16_t*)sp.ctx; a.lse_out = sp.want_lse ? buf.lse : nullptr;
+    return attention_bf16(a, s);
+  }
+  const int64_t NN = (int64_t)N * N;
+  auto scores_of = [&](int t, bool accumulate) {
+    GemmF32Args g{};
+    g.A = (const float*)sp.q[t]; g.lda = sp.st; g.sAo = sp.sb; g.sAi = dh;
+    g.B = (const float*)sp.k[t]; g.sbk = 1; g.sbn = sp.st; g.sBo = sp.sb; g.sBi = dh;
+    g.C = buf.scores; g.ldc = N; g.sCo = (int64_t)H * NN; g.sCi = NN;
+    g.residual = accumulate ? buf.scores : nullptr; g.ldr = N;
+    g.M = N; g.N = N; g.K = dh; g.batch = B * H; g.inner = H; g.act = 0; g.alpha = 1.f;
+    return gemm_f32(g, s);
+  };
+  const int64_t rows = (int64_t)B * H * N;
+  if (sp.sum_scores) {
+    for (int t = 0; t < sp.n_terms; ++t) SG_TRY(scores_of(t, t > 0));
+    SG_TRY(softmax_rows(buf.scores, N, rows, N, H, sp.scale_per_image, sp.scale, sp.bias, sp.bias_w, sp.resoftmax ? 1 : 0, 0,
+                        buf.probs, sp.want_lse ? buf.lse : nullptr, s));
+  } else {
+    for (int t = 0; t < sp.n_terms; ++t) {
+      SG_TRY(scores_of(t, false));
+      SG_TRY(softmax_rows(buf.scores, N, rows, N, H, sp.scale_per_image, sp.scale, sp.bias, sp.bias_w, 0, t > 0, buf.probs,
+                          (sp.want_lse && t == 0) ? buf.lse : nullptr, s));
+    }
+  }
+  GemmF32Args g{};
+  g.A = buf.probs; g.lda = N; g.sAo = (int64_t)H * NN; g.sAi = NN;
+  g.B = (const float*)sp.v; g.sbk = sp.v_st; g.sbn = 1; g.sBo = sp.v_sb; g.sBi = dh;
+  g.C = (float*)sp.ctx; g.ldc = sp.ctx_st; g.sCo = sp.ctx_sb; g.sCi = dh;
+  g.M = N; g.N = dh; g.K = N; g.batch = B * H; g.inner = H; g.act = 0; g.alpha = sp.out_scale;
+  return gemm_f32(g, s);
+}
+
+// Attention over packed qkv [B,N,3D] (compute dtype) -> ctx [B,N,D] (compute dtype).
+static int run_attention(bool bf16, const void* qkv, int B, int N, int D, int H, int model_type, const float* sim, float sim_w,
+                         const float* scale_per_image, void* ctx, bool want_lse, const AttnBuffers& buf, hipStream_t s) {
+  const int dh = D / H;
+  Variant v;
+  if (!variant_of(model_type, v)) return fail(SG_ERR_INVALID, "attention variant %d is not built (NACLIP / NOnly / GAV: SURVEY.md §8f rank 3)", model_type);
+  const size_t e = bf16 ? 2 : 4;
+  AttnSpec sp{};
+  for (int t = 0; t < v.n_terms; ++t) { sp.q[t] = (const char*)qkv + (size_t)v.qsel[t] * D * e; sp.k[t] = (const char*)qkv + (size_t)v.ksel[t] * D * e; }
+  sp.v = (const char*)qkv + (size_t)2 * D * e;
+  sp.st = sp.v_st = 3 * (int64_t)D; sp.sb = sp.v_sb = (int64_t)N * 3 * D;
+  sp.n_terms = v.n_terms; sp.sum_scores = v.sum_scores; sp.resoftmax = v.resoftmax;
+  sp.scale = v.scale_mul / sqrtf((float)dh); sp.scale_per_image = scale_per_image;
+  sp.bias = sim; sp.bias_w = sim_w; sp.out_scale = 1.f;
+  sp.ctx = ctx; sp.ctx_sb = (int64_t)N * D; sp.ctx_st = D; sp.want_lse = want_lse;
+  return attn_generic(bf16, sp, B, N, H, dh, buf, s);
+}
+
+// y = act(A . W^T + bias) (+ residual) in the context's compute dtype; out_f32 forces an f32 C.
+static int linear(bool bf16, const void* A, int64_t lda, const void* W, const float* bias, const float* residual, void* C,
+                  int64_t ldc, bool c_f32, int M, int N, int K, int act, hipStream_t s) {
+  if (bf16) {
+    GemmBf16Args g{};
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
+    g.C = C; g.ldc = ldc; g.c_is_bf16 = c_f32 ? 0 : 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f;
+    return gemm_bf16(g, s);
+  }
+  GemmF32Args g{};
+  g.A = (const float*)A; g.lda = lda; g.B = (const float*)W; g.sbk = 1; g.sbn = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
+  g.C = (float*)C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.batch = 1; g.inner = 1; g.act = act; g.alpha = 1.f;
+  return gemm_f32(g, s);
+}
+
+__global__ void zero_diag_kernel(float* sim, int n, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) sim[(i / n) * (int64_t)n * n + (i % n) * (int64_t)(n + 1)] = 0.f;
+}
+__global__ void unpack_bf16_kernel(const bf16_t* src, float* dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = bf2f(src[i]);
+}
+
+// similarity map from L2-normalised patch rows xhat [B,n,D] (compute dtype) -> sim [B,n,n] f32
+static int similarity_from_xhat(bool bf16, const void* xhat, int B, int n, int D, float temperature, int add_self, float* sim, hipStream_t s) {
+  if (bf16) {
+    GemmBf16Args g{};
+    g.A = (const bf16_t*)xhat; g.lda = D; g.strideA = (int64_t)n * D; g.W = (const bf16_t*)xhat; g.ldw = D; g.strideW = (int64_t)n * D;
+    g.C = sim; g.ldc = n; g.strideC = (int64_t)n * n; g.c_is_bf16 = 0; g.M = n; g.N = n; g.K = D; g.batch = B; g.act = 0;
+    g.alpha = 1.0f / temperature;
+    SG_TRY(gemm_bf16(g, s));
+  } else {
+    GemmF32Args g{};
+    g.A = (const float*)xhat; g.lda = D; g.sAo = (int64_t)n * D; g.B = (const float*)xhat; g.sbk = 1; g.sbn = D; g.sBo = (int64_t)n * D;
+    g.C = sim; g.ldc = n; g.sCo = (int64_t)n * n; g.M = n; g.N = n; g.K = D; g.batch = B; g.inner = 1; g.act = 0; g.alpha = 1.0f / temperature;
+    SG_TRY(gemm_f32(g, s));
+  }
+  if (!add_self) {
+    const int64_t total = (int64_t)B * n;
+    hipLaunchKernelGGL(zero_diag_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, sim, n, total);
+    SG_LAUNCH_CHECK();
+  }
+  return SG_OK;
+}
+
+// ---- workspace plan of one forward (shared by the size query and the forward itself) ---------------------------------
+struct Plan {
+  void *patchA; float* patchOut; float* pos_r; float* x; void* xn; void* qkv; void* ctx; void* hbuf; void* xhat; float* sim;
+  float *lse, *lse1, *attn_cls, *attn_diag, *out_last, *y; int32_t *idx_out, *idx_sa; void* refine_scratch;
+  float *scores, *probs;
+  // GEM
+  float* x_gem; void* gnorm[3]; void* gatt[3]; float* inv_temp; float* gem_out; void* ctx2;
+};
+
+static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_opts* o, void* ws, bool dry, Plan& p) {
+  const sg_vit_desc& d = c->d;
+  const int n = gh * gw, N = n + 1;
+  const int64_t R = (int64_t)B * N;
+  const size_t e = c->esz;
+  Bump b(ws, 0, dry);
+  p.patchA = b.take((size_t)B * n * c->Kpad * e);
+  p.patchOut = b.get<float>((size_t)B * n * d.width);
+  p.pos_r = b.get<float>((size_t)N * d.width);
+  p.x = b.get<float>(R * d.width);
+  p.xn = b.take(R * d.width * e);
+  p.qkv = b.take(R * 3 * d.width * e);
+  p.ctx = b.take(R * d.width * e);
+  p.hbuf = b.take(R * d.mlp_width * e);
+  p.xhat = nullptr; p.sim = nullptr;
+  if (o->similarity_enabled) { p.xhat = b.take((size_t)B * n * d.width * e); p.sim = b.get<float>((size_t)B * n * n); }
+  p.lse = b.get<float>((size_t)B * d.heads * N);
+  p.lse1 = b.get<float>((size_t)B * d.heads * N);
+  p.attn_cls = b.get<float>((size_t)B * N);
+  p.attn_diag = b.get<float>((size_t)B * N);
+  p.out_last = b.get<float>(R * d.width);
+  p.y = b.get<float>(R * d.embed_dim);
+  const int k_out = o->outlier_enabled ? (o->outlier_top_k < n ? o->outlier_top_k : n) : 0;
+  const int k_sa = (o->outlier_enabled && o->selfattn_enabled) ? (o->selfattn_top_k < n ? o->selfattn_top_k : n) : 0;
+  p.idx_out = b.get<int32_t>((size_t)B * (k_out > 0 ? k_out : 1));
+  p.idx_sa = b.get<int32_t>((size_t)B * (k_sa > 0 ? k_sa : 1));
+  const int kmax = k_out > k_sa ? k_out : k_sa;
+  p.refine_scratch = b.take(refine_scratch_bytes(B, d.width, kmax > 0 ? kmax : 1));
+  p.scores = p.probs = nullptr;
+  if (!c->bf16) { p.scores = b.get<float>((size_t)B * d.heads * N * N); p.probs = b.get<float>((size_t)B * d.heads * N * N); }
+  p.x_gem = nullptr;
+  if (o->model_type == SG_GEM) {
+    p.x_gem = b.get<float>(R * d.width);
+    p.gem_out = b.get<float>(R * d.width);
+    for (int t = 0; t < 3; ++t) { p.gnorm[t] = b.take(R * d.width * e); p.gatt[t] = b.take(R * d.width * e); }
+    p.ctx2 = b.take(R * d.width * e);
+    p.inv_temp = b.get<float>(B);
+  }
+  return align_up(b.off, 256);
+}
+
+static int find_layer_tensor(const char* rest, int& slot) {
+  static const char* names[12] = {"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                                  "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                                  "mlp.c_proj.weight", "mlp.c_proj.bias"};
+  for (int i = 0; i < 12; ++i) if (!strcmp(rest, names[i])) { slot = i; return 1; }
+  return 0;
+}
+
+}  // namespace sg
+
+extern "C" const char* sg_last_error(void) { return g_err; }
+extern "C" int sg_version(void) { return 100; }
+
+extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) {
+  SG_REQUIRE(out && desc, "sg_create: null argument");
+  const sg_vit_desc& d = *desc;
+  SG_REQUIRE(d.width > 0 && d.layers >= 2 && d.heads > 0 && d.width % d.heads == 0 && d.patch > 0 && d.embed_dim > 0 && d.grid0 > 0 &&
+             d.mlp_width > 0, "sg_create: bad descriptor");
+  SG_REQUIRE(d.precision == SG_PREC_F32 || d.precision == SG_PREC_BF16, "sg_create: bad precision %d", d.precision);
+  SG_REQUIRE(d.width % 4 == 0 && d.embed_dim % 4 == 0, "sg_create: width / embed_dim must be multiples of 4");
+  if (d.precision == SG_PREC_BF16) {
+    SG_REQUIRE(d.width % 64 == 0 && d.mlp_width % 64 == 0, "sg_create: bf16 mode needs width and mlp_width to be multiples of 64");
+    const int dh = d.width / d.heads;
+    SG_REQUIRE(dh == 32 || dh == 64 || dh == 80 || dh == 128, "sg_create: bf16 mode supports head_dim 32/64/80/128, got %d", dh);
+  }
+  SG_HIP(hipSetDevice(device));
+  sg_context* c = new sg_context();
+  c->d = d; c->device = device; c->bf16 = d.precision == SG_PREC_BF16; c->esz = c->bf16 ? 2 : 4;
+  c->Kpatch = 3 * d.patch * d.patch;
+  c->Kpad = (int)align_up(c->Kpatch, 64);
+  c->finalized = false;
+  c->n_expected = expected_tensors(d);
+  c->have.assign(c->n_expected, 0);
+  // arena: all packed weights
+  Bump b(nullptr, 0, true);
+  auto lay = [&](Bump& bb) {
+    const size_t e = c->esz; const int D = d.width, M = d.mlp_width;
+    c->w_patch = bb.take((size_t)D * c->Kpad * e);
+    c->w_projT = bb.take((size_t)d.embed_dim * D * e);
+    c->cls_emb = bb.get<float>(D);
+    c->pos = bb.get<float>((size_t)(d.grid0 * d.grid0 + 1) * D);
+    c->lnpre_g = bb.get<float>(D); c->lnpre_b = bb.get<float>(D); c->lnpost_g = bb.get<float>(D); c->lnpost_b = bb.get<float>(D);
+    c->layers.resize(d.layers);
+    for (auto& L : c->layers) {
+      L.w_qkv = bb.take((size_t)3 * D * D * e); L.w_out = bb.take((size_t)D * D * e);
+      L.w_fc = bb.take((size_t)M * D * e); L.w_proj = bb.take((size_t)D * M * e);
+      L.b_qkv = bb.get<float>(3 * D); L.b_out = bb.get<float>(D); L.b_fc = bb.get<float>(M); L.b_proj = bb.get<float>(D);
+      L.ln1_g = bb.get<float>(D); L.ln1_b = bb.get<float>(D); L.ln2_g = bb.get<float>(D); L.ln2_b = bb.get<float>(D);
+    }
+  };
+  lay(b);
+  c->arena_bytes = align_up(b.off, 256);
+  hipError_t e = hipMalloc(&c->arena, c->arena_bytes);
+  if (e != hipSuccess) { delete c; return fail(SG_ERR_HIP, "sg_create: hipMalloc(%zu) -> %s", c->arena_bytes, hipGetErrorString(e)); }
+  Bump real(c->arena, c->arena_bytes, false);
+  lay(real);
+  *out = c;
+  return SG_OK;
+}
+
+extern "C" void sg_destroy(sg_context* c) {
+  if (!c) return;
+  if (c->arena) (void)hipFree(c->arena);
+  delete c;
+}
+
+extern "C" int sg_vit_set_tensor(sg_context* c, const char* name, const float* src, int64_t numel, sg_stream st) {
+  SG_REQUIRE(c && name && src, "sg_vit_set_tensor: null argument");
+  hipStream_t s = as_stream(st);
+  const sg_vit_desc& d = c->d;
+  const int D = d.width, M = d.mlp_width, E = d.embed_dim;
+  const int to_bf16 = c->bf16 ? 1 : 0;
+  auto copyf = [&](float* dst, int64_t n) -> int {
+    SG_REQUIRE(numel == n, "sg_vit_set_tensor(%s): expected %lld elements, got %lld", name, (long long)n, (long long)numel);
+    SG_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return SG_OK;
+  };
+  auto packw = [&](void* dst, int rows, int cols, int cols_pad) -> int {
+    SG_REQUIRE(numel == (int64_t)rows * cols, "sg_vit_set_tensor(%s): expected %lld elements, got %lld", name, (long long)rows * cols, (long long)numel);
+    return pack_rows(src, rows, cols, cols, dst, cols_pad, to_bf16, s);
+  };
+  int slot = -1, rc = SG_OK;
+  if (!strcmp(name, "conv1.weight")) { slot = 0; rc = packw(c->w_patch, D, c->Kpatch, c->Kpad); }
+  else if (!strcmp(name, "class_embedding")) { slot = 1; rc = copyf(c->cls_emb, D); }
+  else if (!strcmp(name, "positional_embedding")) { slot = 2; rc = copyf(c->pos, (int64_t)(d.grid0 * d.grid0 + 1) * D); }
+  else if (!strcmp(name, "ln_pre.weight")) { slot = 3; rc = copyf(c->lnpre_g, D); }
+  else if (!strcmp(name, "ln_pre.bias")) { slot = 4; rc = copyf(c->lnpre_b, D); }
+  else if (!strcmp(name, "ln_post.weight")) { slot = 5; rc = copyf(c->lnpost_g, D); }
+  else if (!strcmp(name, "ln_post.bias")) { slot = 6; rc = copyf(c->lnpost_b, D); }
+  else if (!strcmp(name, "proj")) {
+    slot = 7;
+    SG_REQUIRE(numel == (int64_t)D * E, "sg_vit_set_tensor(proj): expected %d x %d", D, E);
+    rc = transpose_pack(src, D, E, c->w_projT, to_bf16, s);
+  } else {
+    int li = -1, consumed = 0;
+    if (sscanf(name, "transformer.resblocks.%d.%n", &li, &consumed) == 1 && consumed > 0 && li >= 0 && li < d.layers) {
+      int t;
+      if (find_layer_tensor(name + consumed, t)) {
+        LayerW& L = c->layers[li];
+        slot = 8 + li * 12 + t;
+        switch (t) {
+          case 0: rc = copyf(L.ln1_g, D); break;
+          case 1: rc = copyf(L.ln1_b, D); break;
+          case 2: rc = packw(L.w_qkv, 3 * D, D, D); break;
+          case 3: rc = copyf(L.b_qkv, 3 * D); break;
+          case 4: rc = packw(L.w_out, D, D, D); break;
+          case 5: rc = copyf(L.b_out, D); break;
+          case 6: rc = copyf(L.ln2_g, D); break;
+          case 7: rc = copyf(L.ln2_b, D); break;
+          case 8: rc = packw(L.w_fc, M, D, D); break;
+          case 9: rc = copyf(L.b_fc, M); break;
+          case 10: rc = packw(L.w_proj, D, M, M); break;
+          case 11: rc = copyf(L.b_proj, D); break;
+        }
+      }
+    }
+  }
+  if (slot < 0) return fail(SG_ERR_INVALID, "sg_vit_set_tensor: unknown tensor name '%s'", name);
+  if (rc != SG_OK) return rc;
+  c->have[slot] = 1;
+  c->finalized = false;
+  return SG_OK;
+}
+
+extern "C" int sg_vit_finalize(sg_context* c, sg_stream) {
+  SG_REQUIRE(c, "sg_vit_finalize: null context");
+  int missing = 0;
+  for (int i = 0; i < c->n_expected; ++i) if (!c->have[i]) ++missing;
+  if (missing) return fail(SG_ERR_STATE, "sg_vit_finalize: %d of %d tensors were never set", missing, c->n_expected);
+  c->finalized = true;
+  return SG_OK;
+}
+
+extern "C" size_t sg_vit_workspace_bytes(const sg_context* c, int n_tiles, int gh, int gw, const sg_forward_opts* o) {
+  if (!c || !o || n_tiles <= 0 || gh <= 0 || gw <= 0) return 0;
+  Plan p;
+  return plan(c, n_tiles, gh, gw, o, nullptr, true, p);
+}
+
+static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int64_t R, hipStream_t s) {
+  const sg_vit_desc& d = c->d;
+  const int D = d.width, M = d.mlp_width;
+  const int act = d.quick_gelu ? ACT_QUICK_GELU : ACT_GELU;
+  SG_TRY(layernorm(x, D, L.ln2_g, L.ln2_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+  SG_TRY(linear(c->bf16, p.xn, D, L.w_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
+  SG_TRY(linear(c->bf16, p.hbuf, M, L.w_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s));
+  return SG_OK;
+}
+
+// One ordinary residual block (reference open_clip/transformer.py:234-254), x updated in place.
+static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int B, int N, bool stats, hipStream_t s) {
+  const sg_vit_desc& d = c->d;
+  const int D = d.width, H = d.heads;
+  const int64_t R = (int64_t)B * N;
+  AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1};
+  SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+  SG_TRY(linear(c->bf16, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+  SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s));
+  if (stats)
+    SG_TRY(attention_stats(p.qkv, c->bf16, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), p.attn_cls,
+                           p.attn_diag, s));
+  SG_TRY(linear(c->bf16, p.ctx, D, L.w_out, L.b_out, x, x, D, true, (int)R, D, D, ACT_NONE, s));
+  return mlp_block(c, L, x, p, R, s);
+}
+
+static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan& p, int B, int N, hipStream_t s);
+
+extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const sg_forward_opts* o, float* out_cls, float* out_tokens,
+                              void* workspace, size_t workspace_bytes, sg_stream st) {
+  SG_REQUIRE(c && tiles && o && out_tokens && workspace, "sg_vit_forward: null argument");
+  if (!c->finalized) return fail(SG_ERR_STATE, "sg_vit_forward: weights not finalized (call sg_vit_finalize)");
+  hipStream_t s = as_stream(st);
+  const sg_vit_desc& d = c->d;
+  const int B = tiles->n_tiles, gh = tiles->grid_h, gw = tiles->grid_w, n = gh * gw, N = n + 1;
+  const int D = d.width, H = d.heads, L = d.layers, E = d.embed_dim;
+  const int64_t R = (int64_t)B * N;
+  SG_REQUIRE(B > 0 && gh > 0 && gw > 0, "sg_vit_forward: empty batch");
+  SG_REQUIRE(tiles->scene && tiles->windows, "sg_vit_forward: null scene / windows");
+  SG_REQUIRE(o->model_type == SG_GEM || out_cls, "sg_vit_forward: out_cls required");
+  SG_REQUIRE(R * (int64_t)(d.mlp_width > 3 * D ? d.mlp_width : 3 * D) < (1ll << 40), "sg_vit_forward: batch too large");
+  if (o->outlier_enabled || o->selfattn_enabled) SG_REQUIRE(gh == gw, "sg_vit_forward: refiners need a square patch grid (reference transformer.py:583)");
+  if (o->outlier_enabled) SG_REQUIRE(o->outlier_top_k >= 1, "sg_vit_forward: outlier_top_k must be >= 1");
+  if (o->selfattn_enabled && o->outlier_enabled && o->selfattn_mode != 0)
+    return fail(SG_ERR_INVALID, "sg_vit_forward: self-attention enhancement mode='attention' is not built (SURVEY.md §8f rank 3)");
+  Plan p;
+  const size_t need = plan(c, B, gh, gw, o, workspace, false, p);
+  if (need > workspace_bytes) return fail(SG_ERR_STATE, "sg_vit_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
+  SG_REQUIRE((((uintptr_t)workspace) & 255) == 0, "sg_vit_forward: workspace must be 256-byte aligned");
+
+  // ---- prologue: patch embed, class token, positional embedding, ln_pre (transformer.py:559-576) ----
+  const bool gem = o->model_type == SG_GEM;
+  SG_TRY(patchify(*tiles, d.patch, p.patchA, c->Kpad, c->bf16, s));
+  SG_TRY(linear(c->bf16, p.patchA, c->Kpad, c->w_patch, nullptr, nullptr, p.patchOut, D, true, B * n, D, c->Kpad, ACT_NONE, s));
+  const float* pos = c->pos;
+  if (gh != d.grid0 || gw != d.grid0) { SG_TRY(posembed_resize(c->pos, d.grid0, D, gh, gw, gem ? 1 : 0, p.pos_r, s)); pos = p.pos_r; }
+  SG_TRY(embed_assemble(p.patchOut, D, c->cls_emb, pos, c->lnpre_g, c->lnpre_b, p.x, B, N, D, 1e-5f, s));
+
+  if (gem) {
+    const int first = L - (o->gem_depth - 1);
+    SG_REQUIRE(o->gem_depth >= 2 && first >= 0, "sg_vit_forward: gem_depth %d does not fit %d layers", o->gem_depth, L);
+    for (int i = 0; i < first; ++i) SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, false, s));
+    SG_TRY(gem_forward_tail(c, o, p, B, N, s));
+    SG_TRY(layernorm(p.x_gem, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+  } else {
+    const int mid = (L - 1) / 2;                                      // transformer.py:593
+    const bool want_stats = o->outlier_enabled != 0;                  // transformer.py:609 (R6)
+    for (int i = 0; i < L - 1; ++i) {
+      if (i == mid && o->similarity_enabled)                          // normalised mid-layer patches (similarity_enhancement.py:49)
+        SG_TRY(l2norm_rows(p.x + D, 0, (int64_t)N * D, D, n, p.xhat, c->bf16, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));
+      SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, want_stats && i == L - 2, s));
+    }
+    if (o->similarity_enabled)
+      SG_TRY(similarity_from_xhat(c->bf16, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s));
+    // ---- last block: self-self attention on ln_1(x), no residual / MLP when ignore_residual (transformer.py:627-643) ----
+    const LayerW& LL = c->layers[L - 1];
+    AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1};
+    SG_TRY(layernorm(p.x, D, LL.ln1_g, LL.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+    SG_TRY(linear(c->bf16, p.xn, D, LL.w_qkv, LL.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+    const void* ctx = p.ctx; int64_t ctx_ld = D;
+    if (o->model_type == SG_MASKCLIP) { ctx = (const char*)p.qkv + (size_t)2 * D * c->esz; ctx_ld = 3 * D; }   // identity attention: ctx = v
+    else SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, o->model_type, o->similarity_enabled ? p.sim : nullptr, o->similarity_weight,
+                              nullptr, p.ctx, false, ab, s));
+    SG_TRY(linear(c->bf16, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
+    if (!o->ignore_residual) SG_TRY(mlp_block(c, LL, p.out_last, p, R, s));
+    // ---- refinements on the last-block output (transformer.py:698-742) ----
+    if (o->outlier_enabled && o->selfattn_enabled) {
+      const int k = o->selfattn_top_k < n ? o->selfattn_top_k : n;
+      SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 1, p.idx_sa, s));
+      SG_TRY(neighbour_refine(p.out_last, (int64_t)N * D, D, p.idx_sa, B, gh, gw, D, k, 0, 0.f, p.refine_scratch, s));
+    }
+    if (o->outlier_enabled) {
+      const int k = o->outlier_top_k < n ? o->outlier_top_k : n;
+      SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 0, p.idx_out, s));
+      SG_TRY(neighbour_refine(p.out_last, (int64_t)N * D, D, p.idx_out, B, gh, gw, D, k, 1, o->outlier_contamination_temp, p.refine_scratch, s));
+    }
+    SG_TRY(layernorm(p.out_last, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+  }
+  // ---- epilogue: `@ proj` on every token (transformer.py:765-770) ----
+  SG_TRY(linear(c->bf16, p.xn, D, c->w_projT, nullptr, nullptr, p.y, E, true, (int)R, E, D, ACT_NONE, s));
+  if (out_cls && !gem)
+    SG_HIP(hipMemcpy2DAsync(out_cls, (size_t)E * 4, p.y, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s));
+  SG_HIP(hipMemcpy2DAsync(out_tokens, (size_t)n * E * 4, p.y + E, (size_t)N * E * 4, (size_t)n * E * 4, B, hipMemcpyDeviceToDevice, s));
+  return SG_OK;
+}
+
+// GEM dual-stream blocks (reference gem/gem_utils.py:60-153).  p.x is the ordinary stream; p.x_gem the GEM stream.
+static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan& p, int B, int N, hipStream_t s) {
+  const sg_vit_desc& d = c->d;
+  const int D = d.width, H = d.heads, L = d.layers, dh = D / H;
+  const int64_t R = (int64_t)B * N;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const int first = L - (o->gem_depth - 1);
+  const bool bf = c->bf16;
+  SG_HIP(hipMemcpyAsync(p.x_gem, p.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
+  AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1};
+  for (int i = first; i < L; ++i) {
+    const LayerW& LW = c->layers[i];
+    // ln_1(x): f32 copy for the temperature (mean token norm, gem_utils.py:79-81), compute-dtype copy for the GEMM
+    SG_TRY(layernorm(p.x, D, LW.ln1_g, LW.ln1_b, p.gem_out, D, 0, R, D, 1e-5f, s));
+    SG_TRY(gem_inv_temp(p.gem_out, B, N, D, scale, p.inv_temp, s));
+    const void* xn = p.gem_out;
+    if (bf) { SG_TRY(pack_rows(p.gem_out, R, D, D, p.xn, D, 1, s)); xn = p.xn; }
+    SG_TRY(linear(bf, xn, D, LW.w_qkv, LW.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+    // ordinary stream attention -> p.ctx
+    SG_TRY(run_attention(bf, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, false, ab, s));
+    // GEM streams (v, k, q): normalise per head -> self-attend with values = the normalised vectors -> normalise
+    const int64_t st3 = 3 * (int64_t)D;
+    for (int t = 0; t < 3; ++t) {
+      const char* src = (const char*)p.qkv + (size_t)(2 - t) * D * c->esz;
+      SG_TRY(l2norm_rows(src, bf, st3, dh, H, p.gnorm[t], bf, D, dh, R * H, dh, 1e-12f, s));
+      AttnSpec sp{};
+      sp.q[0] = sp.k[0] = sp.v = p.gnorm[t]; sp.sb = sp.v_sb = (int64_t)N * D; sp.st = sp.v_st = D;
+      sp.n_terms = 1; sp.scale = scale; sp.scale_per_image = p.inv_temp; sp.out_scale = 1.f;
+      sp.ctx = p.gatt[t]; sp.ctx_sb = (int64_t)N * D; sp.ctx_st = D;
+      SG_TRY(attn_generic(bf, sp, B, N, H, dh, ab, s));
+      SG_TRY(l2norm_rows(p.gatt[t], bf, D, dh, H, p.gatt[t], bf, D, dh, R * H, dh, 1e-12f, s));
+    }
+    // assignment to V: mean of the three softmax(y y^T * inv_temp) . v   (gem_utils.py:101-117)
+    AttnSpec sp{};
+    for (int t = 0; t < 3; ++t) sp.q[t] = sp.k[t] = p.gatt[t];
+    sp.sb = (int64_t)N * D; sp.st = D;
+    sp.v = (const char*)p.qkv + (size_t)2 * D * c->esz; sp.v_sb = (int64_t)N * st3; sp.v_st = st3;
+    sp.n_terms = 3; sp.scale = scale; sp.scale_per_image = p.inv_temp; sp.out_scale = 1.0f / 3.0f;
+    sp.ctx = p.ctx2; sp.ctx_sb = (int64_t)N * D; sp.ctx_st = D;
+    SG_TRY(attn_generic(bf, sp, B, N, H, dh, ab, s));
+    // shared out_proj: GEM stream (residual optional, gem_utils.py:149-152), then the ordinary stream + MLP
+    SG_TRY(linear(bf, p.ctx2, D, LW.w_out, LW.b_out, o->ignore_residual ? nullptr : p.x_gem, p.x_gem, D, true, (int)R, D, D, ACT_NONE, s));
+    SG_TRY(linear(bf, p.ctx, D, LW.w_out, LW.b_out, p.x, p.x, D, true, (int)R, D, D, ACT_NONE, s));
+    SG_TRY(mlp_block(c, LW, p.x, p, R, s));
+  }
+  return SG_OK;
+}
+
+// ---- stand-alone ops ------------------------------------------------------------------------------------------------------
+extern "C" int sg_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, sg_stream s) {
+  SG_REQUIRE(x && gamma && beta && y, "sg_op_layernorm: null pointer");
+  return layernorm(x, D, gamma, beta, y, D, 0, rows, D, eps, as_stream(s));
+}
+
+extern "C" int sg_op_linear(const float* A, const float* W, const float* bias, const float* residual, float* C, int M, int N, int K,
+                            int act, int precision, void* scratch, size_t scratch_bytes, sg_stream st) {
+  SG_REQUIRE(A && W && C, "sg_op_linear: null pointer");
+  hipStream_t s = as_stream(st);
+  if (precision == SG_PREC_F32) return linear(false, A, K, W, bias, residual, C, N, true, M, N, K, act, s);
+  const int Kp = (int)align_up(K, 64);
+  const size_t need = align_up((size_t)M * Kp * 2, 256) + (size_t)N * Kp * 2;
+  if (!scratch || scratch_bytes < need) return fail(SG_ERR_STATE, "sg_op_linear: scratch %zu < %zu", scratch_bytes, need);
+  bf16_t* a16 = (bf16_t*)scratch;
+  bf16_t* w16 = (bf16_t*)((char*)scratch + align_up((size_t)M * Kp * 2, 256));
+  SG_TRY(pack_rows(A, M, K, K, a16, Kp, 1, s));
+  SG_TRY(pack_rows(W, N, K, K, w16, Kp, 1, s));
+  return linear(true, a16, Kp, w16, bias, residual, C, N, true, M, N, Kp, act, s);
+}
+
+extern "C" int sg_op_attention(const float* qkv, int B, int N, int D, int H, int variant, const float* sim, float sim_weight, float* ctx,
+                               float* attn_cls, float* attn_diag, int precision, void* scratch, size_t scratch_bytes, sg_stream st) {
+  SG_REQUIRE(qkv && ctx && scratch, "sg_op_attention: null pointer");
+  SG_REQUIRE(D % H == 0, "sg_op_attention: D %% H != 0");
+  hipStream_t s = as_stream(st);
+  const int64_t R = (int64_t)B * N;
+  const bool bf = precision == SG_PREC_BF16;
+  Bump b(scratch, scratch_bytes, false);
+  AttnBuffers ab{};
+  ab.lse = b.get<float>((size_t)B * H * N); ab.lse1 = b.get<float>((size_t)B * H * N);
+  void* qkv_c = (void*)qkv; void* ctx_c = ctx;
+  if (bf) { qkv_c = b.take((size_t)R * 3 * D * 2); ctx_c = b.take((size_t)R * D * 2); }
+  else { ab.scores = b.get<float>((size_t)B * H * N * N); ab.probs = b.get<float>((size_t)B * H * N * N); }
+  if (b.off > scratch_bytes) return fail(SG_ERR_STATE, "sg_op_attention: scratch %zu < %zu", scratch_bytes, b.off);
+  if (bf) SG_TRY(pack_rows(qkv, R, 3 * D, 3 * D, qkv_c, 3 * D, 1, s));
+  const bool stats = attn_cls && attn_diag;
+  if (variant == SG_MASKCLIP) return fail(SG_ERR_INVALID, "sg_op_attention: MaskCLIP is the identity (ctx = v)");
+  SG_TRY(run_attention(bf, qkv_c, B, N, D, H, variant, sim, sim_weight, nullptr, ctx_c, stats, ab, s));
+  if (stats) SG_TRY(attention_stats(qkv_c, bf, (int64_t)N * 3 * D, 3 * D, ab.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), attn_cls, attn_diag, s));
+  if (bf) {
+    hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, (const bf16_t*)ctx_c, ctx, R * D);
+    SG_LAUNCH_CHECK();
+  }
+  return SG_OK;
+}
+
+extern "C" int sg_similarity_map(const float* patches, int64_t batch_stride, int ld, int B, int n, int D, float temperature, int add_self,
+                                 int precision, float* sim, void* scratch, size_t scratch_bytes, sg_stream st) {
+  SG_REQUIRE(patches && sim && scratch, "sg_similarity_map: null pointer");
+  hipStream_t s = as_stream(st);
+  const bool bf = precision == SG_PREC_BF16;
+  const size_t need = (size_t)B * n * D * (bf ? 2 : 4);
+  if (scratch_bytes < need) return fail(SG_ERR_STATE, "sg_similarity_map: scratch %zu < %zu", scratch_bytes, need);
+  if (bf) SG_REQUIRE(D % 64 == 0, "sg_similarity_map: bf16 mode needs D %% 64 == 0");
+  SG_TRY(l2norm_rows(patches, 0, batch_stride, ld, n, scratch, bf, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));
+  return similarity_from_xhat(bf, scratch, B, n, D, temperature, add_self, sim, s);
+}
+
+extern "C" size_t sg_outlier_scratch_bytes(int B, int D, int k) { return refine_scratch_bytes(B, D, k); }
+
+extern "C" int sg_outlier_suppress(float* feats, const float* attn_cls, const float* attn_diag, int B, int gh, int gw, int D, int top_k,
+                                   float contamination_temp, int32_t* out_idx, void* scratch, sg_stream st) {
+  SG_REQUIRE(feats && attn_cls && attn_diag && out_idx && scratch, "sg_outlier_suppress: null pointer");
+  hipStream_t s = as_stream(st);
+  const int n = gh * gw, N = n + 1, k = top_k < n ? top_k : n;
+  SG_TRY(select_topk(attn_cls, attn_diag, B, N, k, 0, out_idx, s));
+  // feats is patch-only [B,n,D]: token t of the kernels = 1 + cell, so shift the base by one row
+  return neighbour_refine(feats - D, (int64_t)n * D, D, out_idx, B, gh, gw, D, k, 1, contamination_temp, scratch, s);
+}
+
+extern "C" int sg_weak_token_replace(float* feats, const float* attn_diag, int B, int gh, int gw, int D, int top_k, int32_t* out_idx,
+                                     void* scratch, sg_stream st) {
+  SG_REQUIRE(feats && attn_diag && out_idx && scratch, "sg_weak_token_replace: null pointer");
+  hipStream_t s = as_stream(st);
+  const int n = gh * gw, N = n + 1, k = top_k < n ? top_k : n;
+  SG_TRY(select_topk(attn_diag, attn_diag, B, N, k, 1, out_idx, s));
+  return neighbour_refine(feats - D, (int64_t)n * D, D, out_idx, B, gh, gw, D, k, 0, 0.f, scratch, s);
+}

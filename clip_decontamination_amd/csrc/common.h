@@ -1,0 +1,113 @@
+// Shared host/device helpers for libsegearth_hip (gfx950 only; no CUDA dual path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include "../../include/segearth_hip.h"
+
+namespace sg {
+
+typedef uint16_t bf16_t;                                            // raw bf16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;          // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing (no exceptions cross the ABI) -------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define SG_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (call);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return ::sg::fail(SG_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+  } while (0)
+
+#define SG_REQUIRE(cond, ...)                                                                \
+  do {                                                                                       \
+    if (!(cond)) return ::sg::fail(SG_ERR_INVALID, __VA_ARGS__);                             \
+  } while (0)
+
+#define SG_LAUNCH_CHECK()                                                                    \
+  do {                                                                                       \
+    hipError_t _e = hipGetLastError();                                                       \
+    if (_e != hipSuccess)                                                                    \
+      return ::sg::fail(SG_ERR_HIP, "%s:%d launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+  } while (0)
+
+#define SG_TRY(expr)                                                                         \
+  do {                                                                                       \
+    int _rc = (expr);                                                                        \
+    if (_rc != SG_OK) return _rc;                                                            \
+  } while (0)
+
+static inline hipStream_t as_stream(sg_stream s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {                    // round-to-nearest-even, NaN kept
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+
+// ---- wave-level reductions (64 lanes) ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activations of the MLP (reference open_clip/transformer.py:35-38 / nn.GELU)
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_exact(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }
+__device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+enum Act { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
+
+// ---- internal op entry points (defined across the .hip files) -------------------------------------
+// bf16 GEMM: C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual).  A, W bf16 (K contiguous, K % 64 == 0).
+struct GemmBf16Args {
+  const bf16_t* A; int64_t lda; int64_t strideA;      // batch stride (elements)
+  const bf16_t* W; int64_t ldw; int64_t strideW;
+  const float* bias;                                  // [N] or null
+  const float* residual; int64_t ldr;                 // f32 [M,N] or null (batch stride = strideC)
+  void* C; int64_t ldc; int64_t strideC; int c_is_bf16;
+  int M, N, K, batch, act;
+  float alpha;                                        // applied to the accumulator before bias
+};
+int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
+
+// f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];
+// B(k,n) at B[k*sbk + n*sbn]; two-level batch: z -> (z / inner, z % inner).
+struct GemmF32Args {
+  const float* A; int64_t lda; int64_t sAo, sAi;
+  const float* B; int64_t sbk, sbn; int64_t sBo, sBi;
+  const float* bias; const float* residual; int64_t ldr;
+  float* C; int64_t ldc; int64_t sCo, sCi;
+  int M, N, K, batch, inner, act;
+  float alpha;
+};
+int gemm_f32(const GemmF32Args& a, hipStream_t s);
+
+}  // namespace sg

@@ -1,0 +1,213 @@
+// Segmentation head: everything after the vision tower.
+//   cosine_logits : segmentor.py:309-336 (CLS normalise, cls_logits, similarity-weighted global debias),
+//                   :374-379 (L2 normalise, tokens @ T^T, + lambda * cls_logits)
+//   stitch        : segmentor.py:388-391 bilinear upsample of each tile's logits, :436-447 un-pad,
+//                   overlap-add, count-normalise -- fused, write-once per canvas pixel (the reference
+//                   re-writes the whole canvas once per tile)
+//   resize        : F.interpolate(mode='bilinear', align_corners=False) (segmentor.py:449)
+//   postprocess   : segmentor.py:475-489
+// All HBM-bound; one pass over the data each.
+#include "rowops.h"
+
+namespace sg {
+
+// ---- cosine logits -------------------------------------------------------------------------------------------
+// One wave per token.  T (Q x E) is staged once per workgroup in LDS.
+__global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restrict__ tokens, const float* __restrict__ cls,
+                                                            const float* __restrict__ text, int n, int E, int Q, float debias,
+                                                            float lambda, float* __restrict__ logits) {
+  extern __shared__ float sm[];
+  float* sT = sm;                    // [Q][E]
+  float* sC = sm + (size_t)Q * E;    // [E] unit-norm CLS
+  float* sCL = sC + E;               // [Q] cls logits
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool use_cls = cls != nullptr;
+  for (int i = tid; i < Q * E; i += 256) sT[i] = text[i];
+  if (use_cls) {
+    for (int i = tid; i < E; i += 256) sC[i] = cls[(int64_t)b * E + i];
+    __syncthreads();
+    if (wave == 0) {                                       // cls /= ||cls||  (segmentor.py:310)
+      float ss = 0.f;
+      for (int i = lane; i < E; i += 64) ss += sC[i] * sC[i];
+      const float nrm = sqrtf(wave_sum(ss));
+      for (int i = lane; i < E; i += 64) sC[i] = sC[i] / nrm;
+    }
+    __syncthreads();
+    for (int q = wave; q < Q; q += 4) {                    // cls_logits = cls @ T^T  (:311)
+      float d = 0.f;
+      for (int i = lane; i < E; i += 64) d += sC[i] * sT[q * E + i];
+      d = wave_sum(d);
+      if (lane == 0) sCL[q] = d;
+    }
+  }
+  __syncthreads();
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= n) return;
+  const float* f = tokens + ((int64_t)b * n + t) * E;
+  // similarity-weighted debias (:322-336): f' = f - cls * (cos(f, cls) * factor); cls already unit norm,
+  // the reference renormalises it once more (a no-op up to rounding) -- reproduced for fidelity.
+  float ff = 0.f, fc = 0.f, cc = 0.f;
+  for (int i = lane; i < E; i += 64) {
+    const float x = f[i];
+    ff += x * x;
+    if (use_cls) { fc += x * sC[i]; cc += sC[i] * sC[i]; }
+  }
+  ff = wave_sum(ff);
+  float w = 0.f;
+  if (use_cls && debias != 0.f) {
+    fc = wave_sum(fc); cc = wave_sum(cc);
+    w = (fc / (sqrtf(ff) * sqrtf(cc))) * debias;
+  }
+  float nn = 0.f;
+  for (int i = lane; i < E; i += 64) {
+    const float x = (use_cls && debias != 0.f) ? f[i] - sC[i] * w : f[i];
+    nn += x * x;
+  }
+  const float inv = 1.0f / sqrtf(wave_sum(nn));
+  for (int q = 0; q < Q; ++q) {
+    float d = 0.f;
+    for (int i = lane; i < E; i += 64) {
+      const float x = (use_cls && debias != 0.f) ? f[i] - sC[i] * w : f[i];
+      d += (x * inv) * sT[q * E + i];
+    }
+    d = wave_sum(d);
+    if (lane == 0) {
+      if (use_cls && lambda != 0.f) d += sCL[q] * lambda;
+      logits[((int64_t)b * Q + q) * n + t] = d;
+    }
+  }
+}
+
+// ---- bilinear helpers (align_corners=False, ATen area_pixel_compute_source_index) ------------------------------------
+__device__ __forceinline__ void bilinear_tap(int dst, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+  if (in == out) { i0 = i1 = dst; l0 = 1.f; l1 = 0.f; return; }            // same-size resize is an exact identity
+  const float scale = (float)in / (float)out;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src; i0 = i0 > in - 1 ? in - 1 : i0;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0; l0 = 1.f - l1;
+}
+
+// ---- stitch -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stitch_kernel(const float* __restrict__ tile_logits, const int32_t* __restrict__ windows,
+                                                     int T, int Q, int gh, int gw, int up_h, int up_w, int pad_t, int pad_l,
+                                                     int H, int W, float* __restrict__ canvas) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const int64_t plane = (int64_t)H * W;
+  float cnt = 0.f;
+  for (int q = 0; q < Q; ++q) canvas[q * plane + (int64_t)y * W + x] = 0.f;
+  for (int t = 0; t < T; ++t) {                                        // raster order = the reference's add order
+    const int y1 = windows[t * 4 + 0], y2 = windows[t * 4 + 1], x1 = windows[t * 4 + 2], x2 = windows[t * 4 + 3];
+    if (y < y1 || y >= y2 || x < x1 || x >= x2) continue;
+    int ya, yb, xa, xb; float wy0, wy1, wx0, wx1;
+    bilinear_tap(y - y1 + pad_t, gh, up_h, ya, yb, wy0, wy1);
+    bilinear_tap(x - x1 + pad_l, gw, up_w, xa, xb, wx0, wx1);
+    const float* base = tile_logits + (int64_t)t * Q * gh * gw;
+    for (int q = 0; q < Q; ++q) {
+      const float* p = base + (int64_t)q * gh * gw;
+      const float top = p[ya * gw + xa] * wx0 + p[ya * gw + xb] * wx1;
+      const float bot = p[yb * gw + xa] * wx0 + p[yb * gw + xb] * wx1;
+      canvas[q * plane + (int64_t)y * W + x] += top * wy0 + bot * wy1;
+    }
+    cnt += 1.f;
+  }
+  if (cnt > 0.f) for (int q = 0; q < Q; ++q) canvas[q * plane + (int64_t)y * W + x] /= cnt;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ src, int C, int h, int w,
+                                                              float* __restrict__ dst, int H, int W) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  int ya, yb, xa, xb; float wy0, wy1, wx0, wx1;
+  bilinear_tap(y, h, H, ya, yb, wy0, wy1);
+  bilinear_tap(x, w, W, xa, xb, wx0, wx1);
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (int64_t)c * h * w;
+    const float top = p[ya * w + xa] * wx0 + p[ya * w + xb] * wx1;
+    const float bot = p[yb * w + xa] * wx0 + p[yb * w + xb] * wx1;
+    dst[((int64_t)c * H + y) * W + x] = top * wy0 + bot * wy1;
+  }
+}
+
+// ---- postprocess ----------------------------------------------------------------------------------------------------
+constexpr int PP_MAX_Q = 64;
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ logits, const int32_t* __restrict__ query_idx,
+                                                          int Q, int K, int64_t HW, float logit_scale, float prob_thd, int bg_idx,
+                                                          float* __restrict__ probs, int64_t* __restrict__ labels) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  float v[PP_MAX_Q];
+  float mx = -INFINITY;
+  for (int q = 0; q < Q; ++q) { v[q] = logits[q * HW + i] * logit_scale; mx = fmaxf(mx, v[q]); }
+  float sum = 0.f;
+  for (int q = 0; q < Q; ++q) { v[q] = expf(v[q] - mx); sum += v[q]; }
+  float best = -INFINITY; int arg = 0;
+  for (int c = 0; c < K; ++c) {
+    float pc;
+    if (K == Q) pc = v[c] / sum;
+    else {
+      // (probabilities * one_hot).max over queries (segmentor.py:484-486): zeros take part in the max
+      pc = (Q > 0) ? 0.f : -INFINITY;
+      bool any_other = false;
+      float m = -INFINITY;
+      for (int q = 0; q < Q; ++q) { if (query_idx[q] == c) m = fmaxf(m, v[q] / sum); else any_other = true; }
+      pc = any_other ? fmaxf(m, 0.f) : m;
+    }
+    if (probs) probs[c * HW + i] = pc;
+    if (pc > best) { best = pc; arg = c; }                                // first maximum wins (torch argmax)
+  }
+  if (best < prob_thd) arg = bg_idx;
+  labels[i] = arg;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const float* text, int B, int n, int E, int Q,
+                                float global_debias_factor, float cls_token_lambda, float* logits, sg_stream s) {
+  SG_REQUIRE(tokens && text && logits, "sg_cosine_logits: null pointer");
+  SG_REQUIRE(B > 0 && n > 0 && E > 0 && Q > 0 && B < 65536, "sg_cosine_logits: bad shape B=%d n=%d E=%d Q=%d", B, n, E, Q);
+  SG_REQUIRE(cls || (global_debias_factor == 0.f && cls_token_lambda == 0.f), "sg_cosine_logits: cls required for debias / lambda");
+  const size_t lds = ((size_t)Q * E + E + Q) * sizeof(float);
+  SG_REQUIRE(lds <= 160 * 1024, "sg_cosine_logits: Q*E=%d exceeds LDS", Q * E);
+  if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_logits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(cosine_logits_kernel, dim3((unsigned)cdiv(n, 4), (unsigned)B), dim3(256), lds, as_stream(s), tokens, cls, text,
+                     n, E, Q, global_debias_factor, cls_token_lambda, logits);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_stitch(const float* tile_logits, const int32_t* windows, int T, int Q, int gh, int gw, int up_h, int up_w,
+                         int pad_t, int pad_l, int H, int W, float* canvas, sg_stream s) {
+  SG_REQUIRE(tile_logits && windows && canvas, "sg_stitch: null pointer");
+  SG_REQUIRE(T > 0 && Q > 0 && gh > 0 && gw > 0 && H > 0 && W > 0, "sg_stitch: bad shape");
+  SG_REQUIRE(cdiv(H, 4) < 65536, "sg_stitch: canvas too tall for one launch");
+  hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)cdiv(W, 64), (unsigned)cdiv(H, 4)), dim3(256), 0, as_stream(s), tile_logits, windows,
+                     T, Q, gh, gw, up_h, up_w, pad_t, pad_l, H, W, canvas);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_resize_bilinear(const float* src, int C, int h, int w, float* dst, int H, int W, sg_stream s) {
+  SG_REQUIRE(src && dst && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, "sg_resize_bilinear: bad arguments");
+  SG_REQUIRE(cdiv(H, 4) < 65536, "sg_resize_bilinear: too tall");
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)cdiv(W, 64), (unsigned)cdiv(H, 4)), dim3(256), 0, as_stream(s), src, C, h, w, dst, H, W);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_postprocess(const float* logits, const int32_t* query_idx, int Q, int K, int H, int W, float logit_scale,
+                              float prob_thd, int bg_idx, float* probs, int64_t* labels, sg_stream s) {
+  SG_REQUIRE(logits && query_idx && labels, "sg_postprocess: null pointer");
+  SG_REQUIRE(Q > 0 && Q <= PP_MAX_Q && K > 0 && K <= Q, "sg_postprocess: Q=%d K=%d unsupported (Q <= %d)", Q, K, PP_MAX_Q);
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)cdiv(HW, 256)), dim3(256), 0, as_stream(s), logits, query_idx, Q, K, HW,
+                     logit_scale, prob_thd, bg_idx, probs, labels);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}

@@ -1,0 +1,182 @@
+// Training-free token refinements that act on the last-block output (before ln_post):
+//   outlier suppression  (reference outlier_suppression.py:15-61 detection, :115-214 mean interpolation)
+//   weak-token replacement (reference self_attention_enhancement.py:71-150, 247-324)
+// The reference walks the outliers with Python loops and k*8 `.item()` host syncs per tile; here the
+// whole step is three small launches per batch of tiles, no host round trip:
+//   1. select_topk      : top-k of A[cls,i]/(A[i,i]+1e-8) (or the k smallest A[i,i]) per image, in LDS
+//   2. refine_compute   : for every selected token, cosine to its 8 clamped neighbours, the softmax
+//                         weights, the replacement row and the decontaminated neighbour rows, all read
+//                         from the ORIGINAL map, written to scratch
+//   3. refine_scatter   : the reference's write order resolved in parallel -- a neighbour cell takes the
+//                         value of the LAST (outlier, neighbour) pair that targets it, cells equal to the
+//                         outlier itself are skipped, outlier cells are written last (they always win).
+#include "rowops.h"
+
+namespace sg {
+
+__constant__ int c_dy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+__constant__ int c_dx[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+
+// ---- 1. top-k selection --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_topk_kernel(const float* __restrict__ attn_cls, const float* __restrict__ attn_diag,
+                                                          int N, int k, int mode, int32_t* __restrict__ idx) {
+  extern __shared__ float vals[];                       // n scores, larger = selected first
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  __shared__ int winner;
+  const int b = blockIdx.x, n = N - 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n; i += 256) {
+    const float d = attn_diag[(int64_t)b * N + 1 + i];
+    vals[i] = mode == 0 ? attn_cls[(int64_t)b * N + 1 + i] / (d + 1e-8f) : -d;
+  }
+  __syncthreads();
+  for (int r = 0; r < k; ++r) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+      const float v = vals[i];
+      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = red_v[0]; int fi = red_i[0];
+      for (int w = 1; w < 4; ++w)
+        if (red_v[w] > fv || (red_v[w] == fv && red_i[w] < fi)) { fv = red_v[w]; fi = red_i[w]; }
+      if (fi == 0x7fffffff) fi = 0;                     // all -inf / NaN: degenerate input
+      winner = fi;
+      idx[(int64_t)b * k + r] = fi;
+      vals[fi] = -INFINITY;
+    }
+    __syncthreads();
+    (void)winner;
+  }
+}
+
+int select_topk(const float* attn_cls, const float* attn_diag, int B, int N, int k, int mode, int32_t* idx, hipStream_t s) {
+  const int n = N - 1;
+  SG_REQUIRE(k >= 1 && k <= n, "select_topk: k=%d out of range for %d patches", k, n);
+  SG_REQUIRE((size_t)n * 4 <= 160 * 1024 - 256, "select_topk: %d patches exceed LDS", n);
+  const size_t lds = (size_t)n * sizeof(float);
+  if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), lds, s, attn_cls, attn_diag, N, k, mode, idx);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// ---- 2. per-outlier neighbourhood arithmetic ------------------------------------------------------------
+// scratch layout per image: [k][9][D] f32 -- row 0 = replacement, rows 1..8 = decontaminated neighbours
+size_t refine_scratch_bytes(int B, int D, int k) { return (size_t)B * k * 9 * D * sizeof(float); }
+
+__global__ __launch_bounds__(256) void refine_compute_kernel(const float* __restrict__ tokens, int64_t sb, int64_t st,
+                                                             const int32_t* __restrict__ idx, int gh, int gw, int D, int k,
+                                                             int decontaminate, float temp, float* __restrict__ scratch) {
+  __shared__ float s_cos[8];
+  __shared__ float s_w[8];
+  __shared__ int s_tok[8];
+  const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cell = idx[(int64_t)b * k + i];
+  const int cy = cell / gw, cx = cell % gw;
+  const float* base = tokens + (int64_t)b * sb;
+  const float* centre = base + (int64_t)(1 + cell) * st;
+  if (tid < 8) {
+    int ny = cy + c_dy[tid], nx = cx + c_dx[tid];
+    ny = ny < 0 ? 0 : (ny > gh - 1 ? gh - 1 : ny);
+    nx = nx < 0 ? 0 : (nx > gw - 1 ? gw - 1 : nx);
+    s_tok[tid] = 1 + ny * gw + nx;
+  }
+  __syncthreads();
+  for (int j = wave; j < 8; j += 4) {                    // F.normalize(eps=1e-12) then dot
+    const float* nb = base + (int64_t)s_tok[j] * st;
+    float dot = 0.f, nn = 0.f, cc = 0.f;
+    for (int d = lane; d < D; d += 64) { const float x = nb[d], c = centre[d]; dot += x * c; nn += x * x; cc += c * c; }
+    dot = wave_sum(dot); nn = wave_sum(nn); cc = wave_sum(cc);
+    if (lane == 0) s_cos[j] = dot / (fmaxf(sqrtf(nn), 1e-12f) * fmaxf(sqrtf(cc), 1e-12f));
+  }
+  __syncthreads();
+  if (tid == 0) {                                        // softmax(clamp(1 - cos, min 0)) over the 8 neighbours
+    float w[8], mx = -INFINITY, sum = 0.f;
+    for (int j = 0; j < 8; ++j) { w[j] = fmaxf(1.0f - s_cos[j], 0.f); mx = fmaxf(mx, w[j]); }
+    for (int j = 0; j < 8; ++j) { w[j] = expf(w[j] - mx); sum += w[j]; }
+    for (int j = 0; j < 8; ++j) s_w[j] = w[j] / sum;
+  }
+  __syncthreads();
+  float* out = scratch + ((int64_t)b * k + i) * 9 * D;
+  for (int d = tid; d < D; d += 256) {
+    const float c = centre[d];
+    float rep = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = base[(int64_t)s_tok[j] * st + d];
+      rep += x * s_w[j];
+      if (decontaminate) {
+        const float sigma = fminf(fmaxf(s_cos[j] * temp, 0.f), 1.f);
+        out[(int64_t)(1 + j) * D + d] = x - c * sigma;
+      }
+    }
+    out[d] = rep;
+  }
+}
+
+// ---- 3. ordered scatter ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refine_scatter_kernel(float* __restrict__ tokens, int64_t sb, int64_t st,
+                                                             const int32_t* __restrict__ idx, int gh, int gw, int D, int k,
+                                                             int decontaminate, const float* __restrict__ scratch) {
+  __shared__ int s_skip;
+  const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int32_t* id = idx + (int64_t)b * k;
+  int target, src_row;
+  if (p < k) {                                           // replacement of outlier p: always written
+    target = id[p]; src_row = p * 9;
+    // duplicates cannot occur in a top-k; if they did, the LAST index wins (advanced-index assignment order)
+    if (tid == 0) { int skip = 0; for (int q = p + 1; q < k; ++q) if (id[q] == target) skip = 1; s_skip = skip; }
+  } else {
+    if (!decontaminate) return;
+    const int pp = p - k, i = pp >> 3, j = pp & 7;
+    const int cell = id[i], cy = cell / gw, cx = cell % gw;
+    int ny = cy + c_dy[j], nx = cx + c_dx[j];
+    ny = ny < 0 ? 0 : (ny > gh - 1 ? gh - 1 : ny);
+    nx = nx < 0 ? 0 : (nx > gw - 1 ? gw - 1 : nx);
+    target = ny * gw + nx; src_row = i * 9 + 1 + j;
+    if (tid == 0) {
+      int skip = (target == cell);                       // clamped onto the outlier itself
+      for (int q = 0; q < k && !skip; ++q) if (id[q] == target) skip = 1;       // an outlier cell: replacement wins
+      for (int q = pp + 1; q < k * 8 && !skip; ++q) {    // a later pair targets the same cell
+        const int qi = q >> 3, qj = q & 7;
+        const int qc = id[qi], qy = qc / gw, qx = qc % gw;
+        int y = qy + c_dy[qj], x = qx + c_dx[qj];
+        y = y < 0 ? 0 : (y > gh - 1 ? gh - 1 : y);
+        x = x < 0 ? 0 : (x > gw - 1 ? gw - 1 : x);
+        if (y * gw + x == target && (y * gw + x) != qc) skip = 1;
+      }
+      s_skip = skip;
+    }
+  }
+  __syncthreads();
+  if (s_skip) return;
+  const float* src = scratch + ((int64_t)b * k * 9 + src_row) * D;
+  float* dst = tokens + (int64_t)b * sb + (int64_t)(1 + target) * st;
+  for (int d = tid; d < D; d += 256) dst[d] = src[d];
+}
+
+int neighbour_refine(float* tokens, int64_t sb, int64_t st, const int32_t* idx, int B, int gh, int gw, int D, int k,
+                     int decontaminate, float contamination_temp, void* scratch, hipStream_t s) {
+  SG_REQUIRE(k >= 1 && k <= gh * gw && B < 65536, "neighbour_refine: bad k=%d", k);
+  hipLaunchKernelGGL(refine_compute_kernel, dim3(k, B), dim3(256), 0, s, tokens, sb, st, idx, gh, gw, D, k, decontaminate,
+                     contamination_temp, (float*)scratch);
+  SG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(refine_scatter_kernel, dim3(decontaminate ? k * 9 : k, B), dim3(256), 0, s, tokens, sb, st, idx, gh, gw, D, k, decontaminate,
+                     (const float*)scratch);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+int attn_mode_enhance(float*, int64_t, int64_t, const float*, const float*, int, int, int, float, float, void*, hipStream_t) {
+  return fail(SG_ERR_INVALID, "self-attention enhancement mode='attention' is not built yet (SURVEY.md §8f rank 3)");
+}
+
+}  // namespace sg

@@ -1,0 +1,363 @@
+// Row-wise (HBM-bound) ops of the ViT: LayerNorm, token assembly (+class token, +positional
+// embedding, ln_pre), positional-embedding resize, f32->bf16 packing, row L2-normalisation and the
+// materialised softmax of parity mode.  One wavefront (64 lanes) per row, float4 loads, shuffle
+// reductions -- no LDS, no atomics.
+#include "rowops.h"
+
+namespace sg {
+
+constexpr int LN_MAX_VEC = 8;      // float4 per lane kept in registers: D <= 64 * 4 * 8 = 2048
+
+template <typename OutT>
+__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  uint2 o; o.x = pack_bf2(a, b); o.y = pack_bf2(c, d);
+  *reinterpret_cast<uint2*>(p) = o;
+}
+
+// Normalise the row held in v[] (nvec float4 per lane) -- reference LayerNorm/LayerNormFp32
+// (open_clip/transformer.py:17-32): biased variance, eps inside the sqrt, f32 arithmetic.
+template <typename OutT>
+__device__ __forceinline__ void ln_row(float4 (&v)[LN_MAX_VEC], int D, int lane, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float eps, OutT* __restrict__ out) {
+  const int nv = D >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+    if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+    if (lane + 64 * i < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * idx);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * idx);
+      store4<OutT>(out + 4 * idx, (v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                   (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+    }
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, OutT* __restrict__ y, int64_t ldy,
+                                                        int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float4 v[LN_MAX_VEC];
+  const int nv = D >> 2;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+    if (lane + 64 * i < nv) v[i] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * i));
+  ln_row<OutT>(v, D, lane, gamma, beta, eps, y + row * ldy);
+}
+
+int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int y_is_bf16,
+              int64_t rows, int D, float eps, hipStream_t s) {
+  SG_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAX_VEC, "layernorm: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * LN_MAX_VEC);
+  SG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: row strides must be multiples of 4");
+  if (rows == 0) return SG_OK;
+  dim3 grid((unsigned)cdiv(rows, 4));
+  if (y_is_bf16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, ldy, rows, D, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (float*)y, ldy, rows, D, eps);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// x[b,t,:] = ln_pre( (t == 0 ? class_embedding : patch_embed[b, t-1, :]) + pos[t, :] )
+// reference open_clip/transformer.py:565-574
+__global__ __launch_bounds__(256) void embed_assemble_kernel(const float* __restrict__ patches, int64_t ldp,
+                                                             const float* __restrict__ cls_emb, const float* __restrict__ pos,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ x, int B, int N, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * N) return;
+  const int b = (int)(row / N), t = (int)(row % N);
+  const float* src = (t == 0) ? cls_emb : patches + ((int64_t)b * (N - 1) + (t - 1)) * ldp;
+  const float* pr = pos + (int64_t)t * D;
+  float4 v[LN_MAX_VEC];
+  const int nv = D >> 2;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+    if (lane + 64 * i < nv) {
+      const float4 a = *reinterpret_cast<const float4*>(src + 4 * (lane + 64 * i));
+      const float4 p = *reinterpret_cast<const float4*>(pr + 4 * (lane + 64 * i));
+      v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+  ln_row<float>(v, D, lane, gamma, beta, eps, x + row * D);
+}
+
+int embed_assemble(const float* patches, int64_t ldp, const float* cls_emb, const float* pos, const float* gamma,
+                   const float* beta, float* x, int B, int N, int D, float eps, hipStream_t s) {
+  SG_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAX_VEC && ldp % 4 == 0, "embed_assemble: unsupported D=%d ldp=%lld", D, (long long)ldp);
+  hipLaunchKernelGGL(embed_assemble_kernel, dim3((unsigned)cdiv((int64_t)B * N, 4)), dim3(256), 0, s, patches, ldp, cls_emb, pos,
+                     gamma, beta, x, B, N, D, eps);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// ---- positional-embedding resize ------------------------------------------------------------------
+// mode 0: F.interpolate(scale_factor=(g+0.1)/g0, mode='bicubic') -- open_clip/transformer.py:777-795
+//         (A = -0.75, align_corners=False, source index not clamped, taps clamped)
+// mode 1: F.interpolate(size=, mode='bicubic', antialias=True)   -- gem/gem_utils.py:12-43
+//         (separable PIL-style filter, A = -0.5, window truncated at the border and renormalised)
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__device__ __forceinline__ int taps_plain(int dst, float scale, int in, int* idx, float* w) {
+  const float A = -0.75f;
+  const float src = scale * ((float)dst + 0.5f) - 0.5f;
+  const float fl = floorf(src);
+  const float t = src - fl;
+  const int i0 = (int)fl;
+  w[0] = cubic2(t + 1.f, A); w[1] = cubic1(t, A); w[2] = cubic1(1.f - t, A); w[3] = cubic2(2.f - t, A);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { int j = i0 - 1 + k; idx[k] = j < 0 ? 0 : (j > in - 1 ? in - 1 : j); }
+  return 4;
+}
+
+constexpr int AA_MAX_TAPS = 24;
+__device__ __forceinline__ float aa_filter(float x) {
+  const float A = -0.5f;
+  x = fabsf(x);
+  if (x < 1.f) return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * A;
+  return 0.f;
+}
+__device__ __forceinline__ int taps_aa(int dst, float scale, int in, int* idx, float* w) {
+  const float support = (scale >= 1.f) ? 2.f * scale : 2.f;
+  const float invscale = (scale >= 1.f) ? 1.f / scale : 1.f;
+  const float center = scale * ((float)dst + 0.5f);
+  int xmin = (int)(center - support + 0.5f); if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5f); if (xmax > in) xmax = in;
+  int n = xmax - xmin; if (n > AA_MAX_TAPS) n = AA_MAX_TAPS;
+  float tot = 0.f;
+  for (int j = 0; j < n; ++j) { w[j] = aa_filter(((float)(j + xmin) - center + 0.5f) * invscale); tot += w[j]; idx[j] = xmin + j; }
+  if (tot != 0.f) for (int j = 0; j < n; ++j) w[j] /= tot;
+  return n;
+}
+
+__global__ void posembed_resize_kernel(const float* __restrict__ pos, int g0, int D, int gh, int gw, float scale_h, float scale_w,
+                                       int mode, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)(gh * gw + 1) * D;
+  if (i >= total) return;
+  const int d = (int)(i % D), t = (int)(i / D);
+  if (t == 0) { out[i] = pos[d]; return; }                       // class position kept
+  const int oy = (t - 1) / gw, ox = (t - 1) % gw;
+  int iy[AA_MAX_TAPS], ix[AA_MAX_TAPS];
+  float wy[AA_MAX_TAPS], wx[AA_MAX_TAPS];
+  const int ny = mode ? taps_aa(oy, scale_h, g0, iy, wy) : taps_plain(oy, scale_h, g0, iy, wy);
+  const int nx = mode ? taps_aa(ox, scale_w, g0, ix, wx) : taps_plain(ox, scale_w, g0, ix, wx);
+  float acc = 0.f;
+  for (int a = 0; a < ny; ++a) {
+    float row = 0.f;
+    for (int b = 0; b < nx; ++b) row += wx[b] * pos[(int64_t)(1 + iy[a] * g0 + ix[b]) * D + d];
+    acc += wy[a] * row;
+  }
+  out[i] = acc;
+}
+
+int posembed_resize(const float* pos, int g0, int D, int gh, int gw, int antialias, float* out, hipStream_t s) {
+  float sh, sw;
+  if (antialias) { sh = (float)g0 / (float)gh; sw = (float)g0 / (float)gw; }
+  else {   // scale = 1 / scale_factor, scale_factor = (g + 0.1) / g0 evaluated in double as Python does
+    sh = (float)(1.0 / (((double)gh + 0.1) / (double)g0));
+    sw = (float)(1.0 / (((double)gw + 0.1) / (double)g0));
+  }
+  if (antialias) SG_REQUIRE(2.f * fmaxf(fmaxf(sh, sw), 1.f) * 2.f + 2.f <= AA_MAX_TAPS, "posembed_resize: downscale %f too large", sh);
+  const int64_t total = (int64_t)(gh * gw + 1) * D;
+  hipLaunchKernelGGL(posembed_resize_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, pos, g0, D, gh, gw, sh, sw, antialias, out);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// ---- f32 -> bf16 pack with optional zero padding of the row (weights, patch matrix K padding) ------
+__global__ void pack_bf16_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld_src, bf16_t* __restrict__ dst,
+                                 int cols_pad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols_pad) return;
+  const int64_t r = i / cols_pad; const int c = (int)(i % cols_pad);
+  dst[i] = c < cols ? f2bf(src[r * ld_src + c]) : (bf16_t)0;
+}
+__global__ void pack_f32_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld_src, float* __restrict__ dst,
+                                int cols_pad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols_pad) return;
+  const int64_t r = i / cols_pad; const int c = (int)(i % cols_pad);
+  dst[i] = c < cols ? src[r * ld_src + c] : 0.f;
+}
+int pack_rows(const float* src, int64_t rows, int cols, int64_t ld_src, void* dst, int cols_pad, int to_bf16, hipStream_t s) {
+  const int64_t total = rows * cols_pad;
+  if (total == 0) return SG_OK;
+  if (to_bf16) hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (bf16_t*)dst, cols_pad);
+  else hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (float*)dst, cols_pad);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// transpose-pack: dst[c][r] = src[r][c]   (proj [D,E] -> W[E,D] so `x @ proj` becomes a W[N,K]^T GEMM)
+__global__ void transpose_pack_kernel(const float* __restrict__ src, int rows, int cols, void* __restrict__ dst, int to_bf16) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int c = (int)(i / rows), r = (int)(i % rows);
+  const float v = src[(int64_t)r * cols + c];
+  if (to_bf16) ((bf16_t*)dst)[i] = f2bf(v); else ((float*)dst)[i] = v;
+}
+int transpose_pack(const float* src, int rows, int cols, void* dst, int to_bf16, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_pack_kernel, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, rows, cols, dst, to_bf16);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// ---- row L2 normalisation: y = x / max(||x||, eps)  (F.normalize, eps 1e-12) --------------------------
+// Rows are (outer, inner) indexed: row r -> x + (r / inner) * so + (r % inner) * si, length D contiguous.
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const InT* __restrict__ x, int64_t so, int64_t si, int inner,
+                                                          OutT* __restrict__ y, int64_t yo, int64_t yi, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const InT* xr = x + (row / inner) * so + (row % inner) * si;
+  OutT* yr = y + (row / inner) * yo + (row % inner) * yi;
+  float ss = 0.f;
+  for (int i = lane; i < D; i += 64) { const float v = to_f32<InT>(xr[i]); ss += v * v; }
+  const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
+  for (int i = lane; i < D; i += 64) yr[i] = from_f32<OutT>(to_f32<InT>(xr[i]) * inv);
+}
+int l2norm_rows(const void* x, int x_bf16, int64_t so, int64_t si, int inner, void* y, int y_bf16, int64_t yo, int64_t yi,
+                int64_t rows, int D, float eps, hipStream_t s) {
+  if (rows == 0) return SG_OK;
+  dim3 grid((unsigned)cdiv(rows, 4));
+  if (!x_bf16 && !y_bf16) hipLaunchKernelGGL((l2norm_rows_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, so, si, inner, (float*)y, yo, yi, rows, D, eps);
+  else if (!x_bf16 && y_bf16) hipLaunchKernelGGL((l2norm_rows_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps);
+  else if (x_bf16 && y_bf16) hipLaunchKernelGGL((l2norm_rows_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps);
+  else hipLaunchKernelGGL((l2norm_rows_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)x, so, si, inner, (float*)y, yo, yi, rows, D, eps);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// ---- materialised softmax of parity mode ----------------------------------------------------------------
+// scores [rows, N] (row stride ld) hold RAW dot products.  Per row r (token i = r % N of image b = r / (H*N)):
+//   mode 0: p = softmax(scale * s + w * bias)            (bias row from sim[b, i-1, :] shifted by the CLS column)
+//   mode 1: p = softmax( softmax(scale * s) + w * bias ) (the 'Experimental' double softmax, transformer.py:896-902)
+// out (+)= p.  lse (optional) receives log-sum-exp of (scale*s [+ w*bias]) for mode 0.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ scores, int64_t ld, int64_t rows, int N, int H,
+                                                           const float* __restrict__ scale_per_image, float scale,
+                                                           const float* __restrict__ bias, float bias_w, int mode,
+                                                           int accumulate, float* __restrict__ out, float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int i = (int)(row % N);
+  const int64_t b = row / ((int64_t)H * N);
+  const float sc = scale_per_image ? scale_per_image[b] : scale;
+  const float* sr = scores + row * ld;
+  float* orow = out + row * ld;
+  const int n = N - 1;
+  const float* brow = (bias && i > 0) ? bias + ((int64_t)b * n + (i - 1)) * n : nullptr;   // sim[b, i-1, :]
+  float mx = -INFINITY;
+  for (int j = lane; j < N; j += 64) {
+    float v = sr[j] * sc;
+    if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1];
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    float v = sr[j] * sc;
+    if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1];
+    sum += expf(v - mx);
+  }
+  sum = wave_sum(sum);
+  if (lse && lane == 0) lse[row] = mx + logf(sum);
+  const float inv = 1.0f / sum;
+  if (mode == 0) {
+    for (int j = lane; j < N; j += 64) {
+      float v = sr[j] * sc;
+      if (brow && j > 0) v += bias_w * brow[j - 1];
+      const float p = expf(v - mx) * inv;
+      orow[j] = accumulate ? orow[j] + p : p;
+    }
+    return;
+  }
+  float mx2 = -INFINITY;
+  for (int j = lane; j < N; j += 64) {
+    float p = expf(sr[j] * sc - mx) * inv;
+    if (brow && j > 0) p += bias_w * brow[j - 1];
+    mx2 = fmaxf(mx2, p);
+  }
+  mx2 = wave_max(mx2);
+  float sum2 = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    float p = expf(sr[j] * sc - mx) * inv;
+    if (brow && j > 0) p += bias_w * brow[j - 1];
+    sum2 += expf(p - mx2);
+  }
+  sum2 = wave_sum(sum2);
+  const float inv2 = 1.0f / sum2;
+  for (int j = lane; j < N; j += 64) {
+    float p = expf(sr[j] * sc - mx) * inv;
+    if (brow && j > 0) p += bias_w * brow[j - 1];
+    const float q = expf(p - mx2) * inv2;
+    orow[j] = accumulate ? orow[j] + q : q;
+  }
+}
+
+int softmax_rows(const float* scores, int64_t ld, int64_t rows, int N, int H, const float* scale_per_image, float scale,
+                 const float* bias, float bias_w, int mode, int accumulate, float* out, float* lse, hipStream_t s) {
+  if (rows == 0) return SG_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, scores, ld, rows, N, H, scale_per_image,
+                     scale, bias, bias_w, mode, accumulate, out, lse);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// ---- small element-wise helpers -------------------------------------------------------------------------
+__global__ void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float a, float b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] + b * y[i];
+}
+int axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s) {
+  if (n == 0) return SG_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, y, x, a, b, n);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// inv_temp[b] = mean_t ||x[b,t,:]|| * scale   (gem/gem_utils.py:79-81)
+__global__ __launch_bounds__(256) void gem_inv_temp_kernel(const float* __restrict__ x, int N, int D, float scale, float* __restrict__ out) {
+  __shared__ float part[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int t = wave; t < N; t += 4) {
+    const float* r = x + ((int64_t)b * N + t) * D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) ss += r[i] * r[i];
+    acc += sqrtf(wave_sum(ss));
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = (part[0] + part[1] + part[2] + part[3]) / (float)N * scale;
+}
+int gem_inv_temp(const float* x, int B, int N, int D, float scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(gem_inv_temp_kernel, dim3(B), dim3(256), 0, s, x, N, D, scale, out);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+}  // namespace sg

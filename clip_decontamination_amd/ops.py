@@ -1,0 +1,211 @@
+"""Thin torch-tensor wrappers over the C ABI (one Python function per exported op).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation happens in
+libsegearth_hip.so.  Nothing in this module falls back to torch arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import PREC_BF16, PREC_F32, MODEL_TYPES, check
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libsegearth_hip ops need device tensors (no CPU fallback exists)")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def precision_id(precision) -> int:
+    if precision in (PREC_F32, "f32", "fp32", torch.float32):
+        return PREC_F32
+    if precision in (PREC_BF16, "bf16", torch.bfloat16):
+        return PREC_BF16
+    raise ValueError(f"unknown precision {precision!r}")
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous().float()
+
+
+def scratch(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256) + 256, dtype=torch.uint8, device=device)
+
+
+def _aligned(buf: torch.Tensor) -> Tuple[C.c_void_p, int]:
+    p = buf.data_ptr()
+    off = (-p) % 256
+    return C.c_void_p(p + off), buf.numel() - off
+
+
+def linear(A, W, bias=None, residual=None, act: int = 0, precision="bf16"):
+    """act(A @ W^T + bias) (+ residual); act 0 none / 1 QuickGELU / 2 erf-GELU."""
+    lib = _lib.load()
+    A, W = _f32(A), _f32(W)
+    _require_gpu(A, W, bias, residual)
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    Kp = (K + 63) // 64 * 64
+    buf = scratch((M + N) * Kp * 2 + 1024, A.device)
+    sp, sn = _aligned(buf)
+    bias = None if bias is None else _f32(bias)
+    residual = None if residual is None else _f32(residual)
+    check(lib.sg_op_linear(ptr(A), ptr(W), ptr(bias), ptr(residual), ptr(out), M, N, K, act, precision_id(precision), sp, sn,
+                           stream_ptr()), "sg_op_linear")
+    return out
+
+
+def layernorm(x, gamma, beta, eps: float = 1e-5):
+    lib = _lib.load()
+    x, gamma, beta = _f32(x), _f32(gamma), _f32(beta)
+    _require_gpu(x, gamma, beta)
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.sg_op_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(y), x.numel() // D, D, eps, stream_ptr()), "sg_op_layernorm")
+    return y
+
+
+def attention(qkv, heads: int, variant: str = "vanilla", sim=None, sim_weight: float = 1.0, precision="bf16",
+              want_stats: bool = False):
+    """Multi-term attention over packed qkv [B,N,3D] -> ctx [B,N,D] (+ head-averaged A[0,:], diag(A))."""
+    lib = _lib.load()
+    qkv = _f32(qkv)
+    _require_gpu(qkv, sim)
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
+    a_cls = torch.empty(B, N, dtype=torch.float32, device=qkv.device) if want_stats else None
+    a_diag = torch.empty(B, N, dtype=torch.float32, device=qkv.device) if want_stats else None
+    pid = precision_id(precision)
+    need = 2 * B * heads * N * 4 + 1024
+    need += (B * N * 4 * D * 2 + 1024) if pid == PREC_BF16 else (2 * B * heads * N * N * 4 + 1024)
+    buf = scratch(need, qkv.device)
+    sp, sn = _aligned(buf)
+    sim = None if sim is None else _f32(sim)
+    check(lib.sg_op_attention(ptr(qkv), B, N, D, heads, MODEL_TYPES[variant], ptr(sim), float(sim_weight), ptr(ctx), ptr(a_cls),
+                              ptr(a_diag), pid, sp, sn, stream_ptr()), "sg_op_attention")
+    return (ctx, a_cls, a_diag) if want_stats else ctx
+
+
+def similarity_map(patches, temperature: float = 1.0, add_self_similarity: bool = True, precision="f32"):
+    """patches [B,n,D] -> cosine self-similarity [B,n,n] (similarity_enhancement.py:37-66)."""
+    lib = _lib.load()
+    patches = _f32(patches)
+    _require_gpu(patches)
+    B, n, D = patches.shape
+    sim = torch.empty(B, n, n, dtype=torch.float32, device=patches.device)
+    buf = scratch(B * n * D * 4 + 1024, patches.device)
+    sp, sn = _aligned(buf)
+    check(lib.sg_similarity_map(ptr(patches), n * D, D, B, n, D, float(temperature), int(add_self_similarity),
+                                precision_id(precision), ptr(sim), sp, sn, stream_ptr()), "sg_similarity_map")
+    return sim
+
+
+def outlier_suppress(feats, attn_cls, attn_diag, gh: int, gw: int, top_k: int = 10, contamination_temp: float = 0.1):
+    """feats [B,gh*gw,D] (returns a refined copy) + the selected indices [B,k]."""
+    lib = _lib.load()
+    feats = _f32(feats).clone()
+    attn_cls, attn_diag = _f32(attn_cls), _f32(attn_diag)
+    _require_gpu(feats, attn_cls, attn_diag)
+    B, n, D = feats.shape
+    k = min(top_k, n)
+    idx = torch.empty(B, k, dtype=torch.int32, device=feats.device)
+    buf = scratch(lib.sg_outlier_scratch_bytes(B, D, k), feats.device)
+    sp, _ = _aligned(buf)
+    check(lib.sg_outlier_suppress(ptr(feats), ptr(attn_cls), ptr(attn_diag), B, gh, gw, D, top_k, float(contamination_temp),
+                                  ptr(idx), sp, stream_ptr()), "sg_outlier_suppress")
+    return feats, idx
+
+
+def weak_token_replace(feats, attn_diag, gh: int, gw: int, top_k: int = 10):
+    lib = _lib.load()
+    feats = _f32(feats).clone()
+    attn_diag = _f32(attn_diag)
+    _require_gpu(feats, attn_diag)
+    B, n, D = feats.shape
+    k = min(top_k, n)
+    idx = torch.empty(B, k, dtype=torch.int32, device=feats.device)
+    buf = scratch(lib.sg_outlier_scratch_bytes(B, D, k), feats.device)
+    sp, _ = _aligned(buf)
+    check(lib.sg_weak_token_replace(ptr(feats), ptr(attn_diag), B, gh, gw, D, top_k, ptr(idx), sp, stream_ptr()),
+          "sg_weak_token_replace")
+    return feats, idx
+
+
+def cosine_logits(tokens, cls, text, global_debias_factor: float = 0.0, cls_token_lambda: float = 0.0):
+    """tokens [B,n,E], cls [B,E] or None, text [Q,E] -> logits [B,Q,n] (segmentor.py:309-336,374-386)."""
+    lib = _lib.load()
+    tokens, text = _f32(tokens), _f32(text)
+    cls = None if cls is None else _f32(cls)
+    _require_gpu(tokens, text, cls)
+    B, n, E = tokens.shape
+    Q = text.shape[0]
+    out = torch.empty(B, Q, n, dtype=torch.float32, device=tokens.device)
+    check(lib.sg_cosine_logits(ptr(tokens), ptr(cls), ptr(text), B, n, E, Q, float(global_debias_factor), float(cls_token_lambda),
+                               ptr(out), stream_ptr()), "sg_cosine_logits")
+    return out
+
+
+def stitch(tile_logits, windows, up_hw, pad_tl, canvas_hw):
+    """tile_logits [T,Q,gh,gw]; windows int32 [T,4] (y1,y2,x1,x2) -> canvas [Q,H,W]."""
+    lib = _lib.load()
+    tile_logits = _f32(tile_logits)
+    windows = windows.to(device=tile_logits.device, dtype=torch.int32).contiguous()
+    _require_gpu(tile_logits)
+    T, Q, gh, gw = tile_logits.shape
+    H, W = canvas_hw
+    canvas = torch.empty(Q, H, W, dtype=torch.float32, device=tile_logits.device)
+    check(lib.sg_stitch(ptr(tile_logits), ptr(windows), T, Q, gh, gw, up_hw[0], up_hw[1], pad_tl[0], pad_tl[1], H, W, ptr(canvas),
+                        stream_ptr()), "sg_stitch")
+    return canvas
+
+
+def resize_bilinear(src, size):
+    """[C,h,w] -> [C,H,W], align_corners=False."""
+    lib = _lib.load()
+    src = _f32(src)
+    _require_gpu(src)
+    Cc, h, w = src.shape
+    H, W = size
+    dst = torch.empty(Cc, H, W, dtype=torch.float32, device=src.device)
+    check(lib.sg_resize_bilinear(ptr(src), Cc, h, w, ptr(dst), H, W, stream_ptr()), "sg_resize_bilinear")
+    return dst
+
+
+def postprocess(logits, query_idx, num_classes: int, logit_scale: float, prob_thd: float, bg_idx: int, want_probs: bool = True):
+    """logits [Q,H,W] -> (probs [K,H,W] or None, labels int64 [1,H,W]) (segmentor.py:475-489)."""
+    lib = _lib.load()
+    logits = _f32(logits)
+    _require_gpu(logits)
+    Q, H, W = logits.shape
+    qi = query_idx.to(device=logits.device, dtype=torch.int32).contiguous()
+    probs = torch.empty(num_classes, H, W, dtype=torch.float32, device=logits.device) if want_probs else None
+    labels = torch.empty(1, H, W, dtype=torch.int64, device=logits.device)
+    check(lib.sg_postprocess(ptr(logits), ptr(qi), Q, num_classes, H, W, float(logit_scale), float(prob_thd), int(bg_idx),
+                             ptr(probs), ptr(labels), stream_ptr()), "sg_postprocess")
+    return probs, labels
+
+
+def adaptive_conv(inp, filters):
+    """FeatUp AdaptiveConv.apply: inp [B,C,h+d-1,w+d-1], filters [B,h,w,d,d] -> [B,C,h,w]."""
+    lib = _lib.load()
+    inp, filters = _f32(inp), _f32(filters)
+    _require_gpu(inp, filters)
+    B, Cc = inp.shape[:2]
+    _, h, w, d, _ = filters.shape
+    out = torch.empty(B, Cc, h, w, dtype=torch.float32, device=inp.device)
+    check(lib.sg_adaptive_conv(ptr(inp), ptr(filters), B, Cc, h, w, d, ptr(out), stream_ptr()), "sg_adaptive_conv")
+    return out

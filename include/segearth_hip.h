@@ -1,0 +1,187 @@
+/*
+ * segearth_hip.h -- C ABI of libsegearth_hip.so: the MI355X (gfx950) implementation of the
+ * sliding-window CLIP dense-feature path of CLIP-Decontamination / SegEarth-OV.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one seam of the
+ * reference's Python hot path; the reference file:line it stands in for is cited on each.
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*;
+ *   - the CALLER owns every input, output and workspace buffer (device memory); the library
+ *     allocates only in sg_create / sg_vit_set_tensor / sg_jbu_set_tensor (packed weights) and
+ *     frees in sg_destroy; no hidden per-call hipMalloc, no host synchronisation in any call
+ *     that takes a stream;
+ *   - every call returns 0 on success or a negative sg_status; the message of the last
+ *     failure on the calling thread is returned by sg_last_error(); nothing aborts or throws;
+ *   - calls are asynchronous on the given stream and re-entrant across contexts.
+ *   - "tokens" are token-major [B, N, D] row-major (N = 1 + gh*gw, CLS first).
+ */
+#ifndef SEGEARTH_HIP_H
+#define SEGEARTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sg_context sg_context;
+typedef void* sg_stream;            /* hipStream_t */
+
+enum sg_status {
+  SG_OK = 0,
+  SG_ERR_INVALID = -1,    /* bad argument / unsupported shape */
+  SG_ERR_HIP = -2,        /* a HIP runtime call failed */
+  SG_ERR_STATE = -3,      /* weights missing, text not set, workspace too small ... */
+};
+
+enum sg_precision {       /* arithmetic the ViT GEMMs / attention run in */
+  SG_PREC_F32 = 0,        /* parity mode: f32 MFMA (exact fmaf chains), materialised attention */
+  SG_PREC_BF16 = 1,       /* throughput mode: bf16 MFMA, f32 accumulate, f32 residual stream + LN */
+};
+
+/* last-block attention variants: reference open_clip/transformer.py:858-932 (custom_attn),
+ * SG_GEM: reference gem/gem_utils.py:60-199 */
+enum sg_model_type {
+  SG_VANILLA = 0, SG_MASKCLIP = 1, SG_CLEARCLIP = 2, SG_SCLIP = 3, SG_SEGEARTH = 4, SG_SFP = 5,
+  SG_EXPERIMENTAL = 6, SG_NACLIP = 7, SG_NONLY = 8, SG_GAV = 9, SG_GEM = 10,
+};
+
+enum sg_image_format {
+  SG_IMG_F32_NCHW = 0,    /* normalised float planes: what predict() receives (segmentor.py:453-467) */
+  SG_IMG_U8_NHWC = 1,     /* raw RGB bytes; (x-mean)/std of segmentor.py:64-67 fused into the load */
+};
+
+/* Architecture of the vision tower: reference open_clip/model_configs/ViT-*.json,
+ * open_clip/transformer.py:341-362 */
+typedef struct sg_vit_desc {
+  int32_t width;          /* D */
+  int32_t layers;         /* L */
+  int32_t heads;          /* H */
+  int32_t patch;          /* P */
+  int32_t embed_dim;      /* E */
+  int32_t grid0;          /* native positional grid side (image_size / patch) */
+  int32_t mlp_width;      /* 4D */
+  int32_t quick_gelu;     /* 1: x*sigmoid(1.702x) (transformer.py:35-38), 0: exact erf GELU */
+  int32_t precision;      /* enum sg_precision */
+} sg_vit_desc;
+
+/* Knobs of one forward: the kwargs of VisionTransformer.forward (transformer.py:538) plus the
+ * refiner modules the reference hangs on net.visual (segmentor.py:196-274). */
+typedef struct sg_forward_opts {
+  int32_t model_type;             /* enum sg_model_type */
+  int32_t ignore_residual;        /* transformer.py:627-643 */
+  int32_t similarity_enabled;     /* similarity_enhancement.py; 0 = module not installed */
+  float   similarity_weight;
+  float   similarity_temperature;
+  int32_t similarity_add_self;
+  int32_t outlier_enabled;        /* outlier_suppression.py; captures block L-2 attention */
+  int32_t outlier_top_k;
+  float   outlier_contamination_temp;
+  int32_t selfattn_enabled;       /* self_attention_enhancement.py (inert unless outlier_enabled, R6) */
+  int32_t selfattn_mode;          /* 0 feature, 1 attention */
+  int32_t selfattn_top_k;
+  float   selfattn_strength;
+  float   selfattn_threshold;
+  int32_t gem_depth;              /* GEM: blocks -1..-(depth-1) are dual-stream (gem_wrapper.py:24-45) */
+} sg_forward_opts;
+
+/* Where the tiles of one launch come from: one scene + a window per tile, so that cropping,
+ * zero padding to a patch multiple (segmentor.py:418-431, 534-546) and im2col happen on the
+ * device in one pass. */
+typedef struct sg_tile_batch {
+  const void* scene;              /* device: [C=3,H,W] f32 planes or [H,W,3] u8 */
+  int32_t format;                 /* enum sg_image_format */
+  int32_t scene_h, scene_w;
+  const int32_t* windows;         /* device int32 [n_tiles][4] = y1,y2,x1,x2 */
+  const int32_t* scene_index;     /* device int32 [n_tiles] image index of each tile, or NULL (all tiles from image 0) */
+  int64_t scene_stride;           /* elements between consecutive images when `scene` holds a batch [B,3,H,W] / [B,H,W,3] */
+  int32_t n_tiles;
+  int32_t tile_h, tile_w;         /* window size (all tiles of a launch share it) */
+  int32_t pad_l, pad_t;           /* compute_padsize(): zeros added left / top */
+  int32_t grid_h, grid_w;         /* (tile + pad) / patch */
+} sg_tile_batch;
+
+const char* sg_last_error(void);
+int sg_version(void);
+
+/* ---- context and weights ------------------------------------------------------------------
+ * sg_create replaces create_model(...) + .eval().to(device) (segmentor.py:69-131) for the
+ * vision tower only; weights arrive by their visual.* state-dict names
+ * (e.g. "transformer.resblocks.3.attn.in_proj_weight", open_clip/transformer.py:372-442). */
+int  sg_create(sg_context** out, int device, const sg_vit_desc* desc);
+void sg_destroy(sg_context* ctx);
+int  sg_vit_set_tensor(sg_context* ctx, const char* name, const float* dev_f32, int64_t numel, sg_stream s);
+int  sg_vit_finalize(sg_context* ctx, sg_stream s);
+
+/* ---- the vision tower -----------------------------------------------------------------------
+ * sg_vit_forward replaces net.encode_image(img, model_type, ignore_residual, output_cls_token=True, ...)
+ * (open_clip/model.py:265-286 -> open_clip/transformer.py:538-775) and, for SG_GEM,
+ * net.visual(img) (gem/gem_utils.py:159-199).
+ *   out_cls    [B,E] f32 (untouched for SG_GEM), out_tokens [B,gh*gw,E] f32. */
+size_t sg_vit_workspace_bytes(const sg_context* ctx, int n_tiles, int grid_h, int grid_w, const sg_forward_opts* o);
+int sg_vit_forward(sg_context* ctx, const sg_tile_batch* tiles, const sg_forward_opts* o,
+                   float* out_cls, float* out_tokens, void* workspace, size_t workspace_bytes, sg_stream s);
+
+/* ---- segmentation head ----------------------------------------------------------------------
+ * sg_cosine_logits replaces segmentor.py:309-336,374-386: CLS normalise + cls_logits, global
+ * debias tokens -= cls * (cos(tokens,cls) * factor), L2 normalise, tokens @ T^T, + lambda*cls_logits.
+ *   tokens [B,n,E], cls [B,E] (may be NULL when both factors are 0), text [Q,E] -> logits [B,Q,n]. */
+int sg_cosine_logits(const float* tokens, const float* cls, const float* text, int B, int n, int E, int Q,
+                     float global_debias_factor, float cls_token_lambda, float* logits, sg_stream s);
+
+/* sg_stitch replaces the bilinear upsample + un-pad + overlap-add + count-normalise of
+ * segmentor.py:388-391,436-447 in a write-once form: canvas[q,y,x] = mean over covering tiles
+ * (raster order) of bilinear(tile_logits)[y - y1 + pad_t, x - x1 + pad_l].
+ *   tile_logits [T,Q,gh,gw] f32, windows int32 [T][4] (y1,y2,x1,x2), canvas [Q,H,W] f32.
+ *   up_h/up_w: the size tiles are bilinearly resized to (tile + pad). */
+int sg_stitch(const float* tile_logits, const int32_t* windows, int T, int Q, int gh, int gw,
+              int up_h, int up_w, int pad_t, int pad_l, int H, int W, float* canvas, sg_stream s);
+
+/* F.interpolate(mode='bilinear', align_corners=False) on [C,h,w] -> [C,H,W] (segmentor.py:389,449) */
+int sg_resize_bilinear(const float* src, int C, int h, int w, float* dst, int H, int W, sg_stream s);
+
+/* sg_postprocess replaces postprocess_result (segmentor.py:475-489): x logit_scale, softmax over
+ * queries, per-class max over synonyms, argmax, prob_thd -> bg_idx.
+ *   logits [Q,H,W]; query_idx int32 [Q]; probs [K,H,W] f32 (may be NULL); labels int64 [H,W]. */
+int sg_postprocess(const float* logits, const int32_t* query_idx, int Q, int K, int H, int W, float logit_scale,
+                   float prob_thd, int bg_idx, float* probs, int64_t* labels, sg_stream s);
+
+/* ---- token refinements as stand-alone ops (same arithmetic as inside sg_vit_forward) ----------
+ * sg_outlier_suppress replaces OutlierSuppressionModule.forward (outlier_suppression.py:83-214):
+ *   feats [B,gh*gw,D] f32 in place; attn_cls [B,N] = head-averaged A[0,:], attn_diag [B,N] = diag(A);
+ *   out_idx int32 [B,k] receives the selected tokens; scratch >= sg_outlier_scratch_bytes. */
+size_t sg_outlier_scratch_bytes(int B, int D, int k);
+int sg_outlier_suppress(float* feats, const float* attn_cls, const float* attn_diag, int B, int gh, int gw, int D,
+                        int top_k, float contamination_temp, int32_t* out_idx, void* scratch, sg_stream s);
+/* SelfAttentionEnhancementModule feature mode (self_attention_enhancement.py:71-150,247-324) */
+int sg_weak_token_replace(float* feats, const float* attn_diag, int B, int gh, int gw, int D, int top_k,
+                          int32_t* out_idx, void* scratch, sg_stream s);
+/* SimilarityEnhancementModule.compute_similarity_map (similarity_enhancement.py:37-66):
+ *   patches [B,n,D] f32 (row stride ld) -> sim [B,n,n] f32 */
+int sg_similarity_map(const float* patches, int64_t batch_stride, int ld, int B, int n, int D, float temperature,
+                      int add_self, int precision, float* sim, void* scratch, size_t scratch_bytes, sg_stream s);
+
+/* ---- building-block ops exported for unit parity tests -----------------------------------------
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual); f32 in/out at the boundary, computed in
+ * `precision`.  act: 0 none, 1 QuickGELU, 2 erf GELU. */
+int sg_op_linear(const float* A, const float* W, const float* bias, const float* residual, float* C,
+                 int M, int N, int K, int act, int precision, void* scratch, size_t scratch_bytes, sg_stream s);
+int sg_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, sg_stream s);
+/* multi-term attention over packed qkv [B,N,3D] (rows q|k|v, nn.MultiheadAttention order);
+ * variant = enum sg_model_type (SG_VANILLA = ordinary softmax(q k^T) v). bias: [B,n,n] or NULL.
+ * Optional outputs: attn_cls/attn_diag [B,N] head-averaged probabilities (vanilla only). */
+int sg_op_attention(const float* qkv, int B, int N, int D, int H, int variant, const float* sim, float sim_weight,
+                    float* ctx, float* attn_cls, float* attn_diag, int precision, void* scratch, size_t scratch_bytes,
+                    sg_stream s);
+
+/* ---- SimFeatUp joint bilateral upsampler --------------------------------------------------------
+ * sg_adaptive_conv mirrors featup.adaptive_conv_cuda AdaptiveConv.apply as called at
+ * simfeatup_dev/upsamplers.py:274 (semantics: adaptive_conv_py_simple, :14-25):
+ *   input [B,C,h+d-1,w+d-1], filters [B,h,w,d,d] -> out [B,C,h,w], all f32. */
+int sg_adaptive_conv(const float* input, const float* filters, int B, int C, int h, int w, int d, float* out, sg_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGEARTH_HIP_H */

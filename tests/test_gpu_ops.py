@@ -1,0 +1,252 @@
+"""GPU parity of the building-block HIP ops, each called through the C ABI, against a plain
+torch fp32 reference of the same op (or the oracle restatement where the op is path-specific).
+
+Tolerances: SG_PREC_F32 runs on the f32 MFMA (exact fmaf chains) -> 2e-4 absolute on O(1) data;
+SG_PREC_BF16 rounds operands to bf16 (8 significant bits, f32 accumulate) -> 3e-2 of the output
+scale for GEMM-shaped ops."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import refine as OR, jbu as OJ, segment as OS   # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from clip_decontamination_amd import ops as o
+    return o
+
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(197, 192, 192), (64, 64, 64), (130, 260, 588), (2740, 3072, 1024), (1370, 1024, 4096), (33, 7, 50)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+def test_linear(ops, M, N, K, prec, tol):
+    A, W, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
+    for act in (0, 1, 2):
+        ref = A @ W.T + b
+        if act == 1:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        elif act == 2:
+            ref = torch.nn.functional.gelu(ref)
+        ref = ref + r
+        out = ops.linear(A.to(DEV), W.to(DEV), b.to(DEV), r.to(DEV), act=act, precision=prec)
+        assert rel_err(out, ref) < tol, (M, N, K, act, rel_err(out, ref))
+    out = ops.linear(A.to(DEV), W.to(DEV), None, None, act=0, precision=prec)
+    assert rel_err(out, A @ W.T) < tol
+
+
+def test_linear_identity_asymmetric(ops):
+    """A = I against an asymmetric W catches a transposed fragment / C layout (guide §3)."""
+    n = 128
+    W = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) / 251.0
+    out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="bf16")
+    assert rel_err(out, W.T.bfloat16().float()) < 1e-6
+    out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="f32")
+    assert rel_err(out, W.T) < 1e-6
+
+
+@pytest.mark.parametrize("rows,D", [(5, 64), (197, 768), (1370, 1024), (3, 1280)])
+def test_layernorm(ops, rows, D):
+    x, g, b = rnd(rows, D, seed=5, scale=3.0) + 0.5, rnd(D, seed=6) * 0.1 + 1, rnd(D, seed=7) * 0.1
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
+    out = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    assert (out.cpu() - ref).abs().max().item() < 1e-5
+
+
+def attention_reference(qkv, H, variant, sim=None, w=1.0):
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // H
+    q, k, v = [t.view(B, N, H, dh).permute(0, 2, 1, 3) for t in qkv.chunk(3, -1)]
+    scale = dh ** -0.5
+
+    def bias(s):
+        if sim is None:
+            return s
+        pad = torch.zeros(B, 1, N, N)
+        pad[:, 0, 1:, 1:] = sim
+        return s + w * pad
+
+    ss = lambda t: (t @ t.transpose(-1, -2)) * scale
+    if variant == "vanilla":
+        a = torch.softmax(bias((q @ k.transpose(-1, -2)) * scale), -1)
+    elif variant == "ClearCLIP":
+        a = torch.softmax(bias(ss(q)), -1)
+    elif variant == "SCLIP":
+        a = torch.softmax(bias(ss(q)), -1) + torch.softmax(bias(ss(k)), -1)
+    elif variant == "SegEarth":
+        a = torch.softmax(bias(ss(q)), -1) + torch.softmax(bias(ss(k)), -1) + torch.softmax(bias(ss(v)), -1)
+    elif variant == "SFP":
+        a = torch.softmax(bias(0.5 * (ss(q) + ss(k))), -1)
+    elif variant == "Experimental":
+        a = torch.softmax(bias(torch.softmax(ss(k) + ss(q), -1)), -1)
+    ctx = (a @ v).permute(0, 2, 1, 3).reshape(B, N, D)
+    return ctx, a
+
+
+SHAPES = [(2, 37, 64, 2), (1, 197, 128, 2), (1, 300, 160, 2), (1, 1370, 128, 2), (2, 65, 256, 2)]
+
+
+@pytest.mark.parametrize("B,N,D,H", SHAPES)
+@pytest.mark.parametrize("variant", ["vanilla", "ClearCLIP", "SCLIP", "SegEarth", "SFP", "Experimental"])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2)])
+def test_attention(ops, B, N, D, H, variant, prec, tol):
+    qkv = rnd(B, N, 3 * D, seed=N + D, scale=1.0)
+    sim = None
+    if variant in ("SegEarth", "Experimental", "ClearCLIP"):
+        f = torch.nn.functional.normalize(rnd(B, N - 1, 24, seed=9), dim=-1)
+        sim = f @ f.transpose(1, 2)
+    ref, _ = attention_reference(qkv, H, variant, sim, 0.8)
+    out = ops.attention(qkv.to(DEV), H, variant, None if sim is None else sim.to(DEV), 0.8, precision=prec)
+    assert rel_err(out, ref) < tol, rel_err(out, ref)
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16", 3e-2)])
+def test_attention_stats(ops, prec, tol):
+    B, N, D, H = 2, 101, 128, 2
+    qkv = rnd(B, N, 3 * D, seed=3)
+    ref, a = attention_reference(qkv, H, "vanilla")
+    am = a.mean(1)
+    ctx, a_cls, a_diag = ops.attention(qkv.to(DEV), H, "vanilla", precision=prec, want_stats=True)
+    assert rel_err(ctx, ref) < max(tol, 2e-5)
+    assert rel_err(a_cls, am[:, 0]) < tol
+    assert rel_err(a_diag, torch.diagonal(am, dim1=-2, dim2=-1)) < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("bf16", 1e-2)])
+def test_similarity_map(ops, golden, prec, tol):
+    g = golden("refine")
+    f = torch.from_numpy(g["sim_feats"])
+    if prec == "bf16":                       # bf16 GEMM needs D % 64 == 0
+        f = torch.cat([f, torch.zeros(*f.shape[:2], 24)], -1)
+    a = ops.similarity_map(f.to(DEV), 1.0, True, prec)
+    b = ops.similarity_map(f.to(DEV), 0.5, False, prec)
+    assert (a.cpu() - torch.from_numpy(g["sim_a"])).abs().max().item() < tol
+    assert (b.cpu() - torch.from_numpy(g["sim_b"])).abs().max().item() < 2 * tol
+
+
+def test_outlier_suppression_matches_reference_fixture(ops, golden):
+    g = golden("refine")
+    grid, attn = torch.from_numpy(g["grid"]), torch.from_numpy(g["attn"])
+    B, D, gh, gw = grid.shape
+    feats = grid.reshape(B, D, gh * gw).permute(0, 2, 1).contiguous()
+    a_cls, a_diag = attn[:, 0].contiguous(), torch.diagonal(attn, dim1=-2, dim2=-1).contiguous()
+    out, idx = ops.outlier_suppress(feats.to(DEV), a_cls.to(DEV), a_diag.to(DEV), gh, gw, 8, 0.1)
+    assert torch.equal(idx.cpu().long(), torch.from_numpy(g["outlier_idx"]))
+    ref = torch.from_numpy(g["suppressed"]).reshape(B, D, gh * gw).permute(0, 2, 1)
+    assert (out.cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_weak_token_replace(ops, golden):
+    g = golden("refine")
+    grid, attn = torch.from_numpy(g["grid"]), torch.from_numpy(g["attn"])
+    B, D, gh, gw = grid.shape
+    feats = grid.reshape(B, D, gh * gw).permute(0, 2, 1).contiguous()
+    a_diag = torch.diagonal(attn, dim1=-2, dim2=-1).contiguous()
+    out, _ = ops.weak_token_replace(feats.to(DEV), a_diag.to(DEV), gh, gw, 6)
+    ref = torch.from_numpy(g["selfattn_feature"]).reshape(B, D, gh * gw).permute(0, 2, 1)
+    assert (out.cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_outlier_edge_cases(ops):
+    """k >= n (every token an outlier), 1x1 and 2x2 grids, adjacent outliers: compare with the oracle."""
+    for gh, k in ((1, 3), (2, 4), (3, 9), (5, 7)):
+        n, D = gh * gh, 16
+        grid = rnd(1, D, gh, gh, seed=gh)
+        attn = torch.softmax(rnd(1, n + 1, n + 1, seed=gh + 10) * 2, -1)
+        idx = OR.detect_outliers(attn, n, k)
+        ref = OR.suppress_outliers(grid, idx, 0.1).reshape(1, D, n).permute(0, 2, 1)
+        feats = grid.reshape(1, D, n).permute(0, 2, 1).contiguous()
+        out, gi = ops.outlier_suppress(feats.to(DEV), attn[:, 0].contiguous().to(DEV),
+                                       torch.diagonal(attn, dim1=-2, dim2=-1).contiguous().to(DEV), gh, gh, k, 0.1)
+        assert torch.equal(gi.cpu().long(), idx)
+        assert (out.cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_cosine_logits(ops):
+    B, n, E, Q = 2, 50, 96, 8
+    tok, cls = rnd(B, n, E, seed=1), rnd(B, E, seed=2)
+    text = torch.nn.functional.normalize(rnd(Q, E, seed=3), dim=-1)
+    for debias, lam in ((0.0, 0.0), (0.2, 0.0), (0.2, -0.3), (0.0, 0.5)):
+        c = cls / cls.norm(dim=-1, keepdim=True)
+        cl = c @ text.T
+        f = tok
+        if debias:
+            sim = ((f / f.norm(dim=-1, keepdim=True)) * (c / c.norm(dim=-1, keepdim=True)).unsqueeze(1)).sum(-1)
+            f = f - c.unsqueeze(1) * (sim.unsqueeze(-1) * debias)
+        f = f / f.norm(dim=-1, keepdim=True)
+        ref = f @ text.T
+        if lam:
+            ref = ref + cl.unsqueeze(1) * lam
+        out = ops.cosine_logits(tok.to(DEV), cls.to(DEV), text.to(DEV), debias, lam)
+        assert (out.cpu() - ref.permute(0, 2, 1)).abs().max().item() < 2e-6
+    out = ops.cosine_logits(tok.to(DEV), None, text.to(DEV))
+    f = tok / tok.norm(dim=-1, keepdim=True)
+    assert (out.cpu() - (f @ text.T).permute(0, 2, 1)).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("src,dst", [((7, 9), (21, 30)), ((14, 14), (224, 224)), ((37, 37), (518, 518)), ((10, 12), (10, 12)), ((16, 16), (9, 11))])
+def test_resize_bilinear(ops, src, dst):
+    x = rnd(5, *src, seed=4)
+    ref = torch.nn.functional.interpolate(x[None], size=dst, mode="bilinear")[0]
+    out = ops.resize_bilinear(x.to(DEV), dst)
+    assert (out.cpu() - ref).abs().max().item() < 2e-6
+
+
+def test_stitch_equals_reference_loop(ops):
+    """Write-once stitch vs the reference's per-tile upsample / un-pad / add / count loop (segmentor.py:416-447)."""
+    Q, H, W, crop, stride, P = 6, 75, 60, 36, 20, 8
+    o = OS.SegOracle.__new__(OS.SegOracle)
+    o.slide_stride, o.slide_crop = stride, crop
+    wins = o.tile_windows(H, W)
+    l, r, t, b = OS.compute_padsize(crop, crop, P)
+    g = (crop + t + b) // P
+    tl = rnd(len(wins), Q, g, g, seed=8)
+    preds, count = torch.zeros(Q, H, W), torch.zeros(1, H, W)
+    for i, (y1, y2, x1, x2) in enumerate(wins):
+        up = torch.nn.functional.interpolate(tl[i][None], size=(crop + t + b, crop + l + r), mode="bilinear")[0]
+        preds[:, y1:y2, x1:x2] += up[:, t:t + (y2 - y1), l:l + (x2 - x1)]
+        count[:, y1:y2, x1:x2] += 1
+    ref = preds / count
+    out = ops.stitch(tl.to(DEV), torch.tensor([[y1, y2, x1, x2] for (y1, y2, x1, x2) in wins]), (crop + t + b, crop + l + r), (t, l), (H, W))
+    assert (out.cpu() - ref).abs().max().item() < 3e-6
+
+
+def test_postprocess(ops, golden):
+    g = golden("segment")
+    qidx = torch.tensor([0, 0, 1, 2, 3, 4, 5, 5])
+    for name, thd, bg in (("ex_base", 0.1, 5), ("ex_pad", 0.0, 0), ("se_plain", 0.0, 0)):
+        logits = torch.from_numpy(g[f"{name}.logits"])[0]
+        o = OS.SegOracle.__new__(OS.SegOracle)
+        o.logit_scale, o.query_idx, o.prob_thd, o.bg_idx = 50.0, qidx, thd, bg
+        p_ref, pred_ref = o.postprocess(logits)
+        probs, labels = ops.postprocess(logits.to(DEV), qidx, 6, 50.0, thd, bg)
+        assert (probs.cpu() - p_ref).abs().max().item() < 1e-5
+        assert torch.equal(labels.cpu(), torch.from_numpy(g[f"{name}.pred"]))
+    # identity class map (K == Q): no synonym merge
+    logits = rnd(5, 9, 11, seed=2) * 0.1
+    probs, labels = ops.postprocess(logits.to(DEV), torch.arange(5), 5, 50.0, 0.3, 2)
+    p = torch.softmax(logits * 50, 0)
+    pred = p.argmax(0, keepdim=True)
+    pred[p.max(0, keepdim=True)[0] < 0.3] = 2
+    assert torch.equal(labels.cpu(), pred) and (probs.cpu() - p).abs().max().item() < 1e-5
+
+
+def test_adaptive_conv(ops, golden):
+    g = golden("jbu")
+    out = ops.adaptive_conv(torch.from_numpy(g["ac_in"]).to(DEV), torch.from_numpy(g["ac_filt"]).to(DEV))
+    assert (out.cpu() - torch.from_numpy(g["ac_out"])).abs().max().item() < 1e-5
