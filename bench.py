@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: segmented Mpix/s, ViT-L/14, 512-pixel tiles, sliding window (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic tiles, inputs resident in HBM:
+  uint8 NHWC scene -> [tile crop + normalise + zero pad + im2col] -> ViT-L/14 (23 ordinary blocks, last block
+  'Experimental' self-self attention + similarity map, outlier suppression k=30: configs/base_config.py)
+  -> global debias + cosine logits (8 Potsdam queries) -> [all-gather of the per-tile logit maps over ranks]
+  -> write-once stitch of this rank's canvas band -> softmax / synonym merge / arg-max labels.
+Scaling is WEAK: every rank processes TILES_PER_RANK tiles of a scene that grows with the rank count;
+value = all ranks' tiles * 512 * 512 / max-over-ranks time.
+
+Also reported in the same JSON line:
+  roofline     -- the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs of its launches / their HIP-event time
+                  (events recorded inside the library on the launch stream during the timed steps)
+  cpu_baseline -- the oracle (CPU restatement pinned to the reference) timed on this host's cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from clip_decontamination_amd import weights as Wt                      # noqa: E402
+
+POTSDAM_QIDX = [0, 0, 1, 2, 3, 4, 5, 5]      # configs/cls_potsdam.txt: 8 queries -> 6 classes
+TILE, STRIDE = 512, 256
+TILE_COLS, TILE_ROWS_PER_RANK = 8, 8         # 64 tiles per rank per step
+PEAK_BF16_TFLOPS = 2500.0                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def build_pipeline(device, precision, tiles_per_launch):
+    from clip_decontamination_amd.engine import HipVisionTower, HipCLIP, SimilarityEnhancementModule, OutlierSuppressionModule
+    from clip_decontamination_amd.pipeline import SegPipeline
+    cfg = Wt.vit_config("ViT-L-14")
+    tower = HipVisionTower(cfg, Wt.make_vit_weights(cfg, seed=0), precision=precision, device=device)
+    tower.similarity_enhancer = SimilarityEnhancementModule(1.0, 1.0, True)
+    tower.outlier_suppressor = OutlierSuppressionModule(top_k=30)
+    text = torch.from_numpy(Wt.make_text_features(len(POTSDAM_QIDX), cfg.embed_dim))
+    pipe = SegPipeline(HipCLIP(tower), text, torch.tensor(POTSDAM_QIDX), model_type="Experimental", ignore_residual=True,
+                       global_debias_factor=0.2, prob_thd=0.1, bg_idx=5, apply_similarity_enhancement=True,
+                       tiles_per_launch=tiles_per_launch)
+    return cfg, pipe
+
+
+def cpu_baseline(cfg, n_tiles=3):
+    """The oracle (port of the reference path, fp32, torch CPU) on a bounded sample of the same workload."""
+    from oracle import segment as OS, vit as OV
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))            # the GPU box gives one GPU a 16-core CPU share
+    torch.set_num_threads(threads)
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    text = torch.from_numpy(Wt.make_text_features(len(POTSDAM_QIDX), cfg.embed_dim))
+    o = OS.SegOracle(cfg, w, text, torch.tensor(POTSDAM_QIDX), model_type="Experimental", global_debias_factor=0.2,
+                     similarity_cfg=dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True),
+                     outlier_cfg=dict(top_k=30), prob_thd=0.1, bg_idx=5, slide_crop=TILE, slide_stride=STRIDE)
+    tiles = torch.from_numpy(Wt.normalize_tiles(Wt.make_tiles_u8(n_tiles + 1, TILE, seed=1234, smooth=True)))
+    with torch.no_grad():
+        o.postprocess(o.forward_slide(tiles[:1])[0])                  # warm-up tile
+        t0 = time.perf_counter()
+        for i in range(1, n_tiles + 1):
+            o.postprocess(o.forward_slide(tiles[i:i + 1])[0])
+        dt = time.perf_counter() - t0
+    return {"value": n_tiles * TILE * TILE / dt / 1e6, "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_tiles} tiles of {TILE}x{TILE} after 1 warm-up, {dt / n_tiles:.2f} s/tile, fp32 torch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--tiles-per-launch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from clip_decontamination_amd import _lib, ops
+    from clip_decontamination_amd.pipeline import tile_windows
+    lib = _lib.load()
+    cfg, pipe = build_pipeline(device, args.precision, args.tiles_per_launch)
+
+    # scene: TILE_COLS x (TILE_ROWS_PER_RANK * world) tiles of 512 at stride 256, uint8 NHWC, resident in HBM
+    rows_total = TILE_ROWS_PER_RANK * world
+    H = STRIDE * (rows_total - 1) + TILE
+    W = STRIDE * (TILE_COLS - 1) + TILE
+    wins = tile_windows(H, W, (STRIDE, STRIDE), (TILE, TILE))
+    assert len(wins) == rows_total * TILE_COLS
+    my = wins[rank * TILE_ROWS_PER_RANK * TILE_COLS:(rank + 1) * TILE_ROWS_PER_RANK * TILE_COLS]
+    band_h = STRIDE * TILE_ROWS_PER_RANK
+    y_lo, y_hi = rank * band_h, (H if rank == world - 1 else (rank + 1) * band_h)
+    # every rank only needs the scene rows its tiles touch; generate that slab deterministically per rank
+    slab_lo, slab_hi = my[0][0], my[-1][1]
+    rng_tiles = Wt.make_tiles_u8(1, max(W, slab_hi - slab_lo), seed=1234 + rank, smooth=True)[0]
+    slab = torch.from_numpy(np.ascontiguousarray(rng_tiles[:slab_hi - slab_lo, :W])).to(device)
+    my_local = [(y1 - slab_lo, y2 - slab_lo, x1, x2) for (y1, y2, x1, x2) in my]
+    win_all = torch.tensor(wins, dtype=torch.int32, device=device)
+    l, r, t, b = 3, 3, 3, 3                                           # compute_padsize(512, 512, 14)
+    up = (TILE + t + b, TILE + l + r)
+
+    def step():
+        tl = pipe.tile_logits(slab, my_local, (TILE, TILE))           # [64, Q, 37, 37]
+        if world > 1:
+            gathered = [torch.empty_like(tl) for _ in range(world)]
+            dist.all_gather(gathered, tl)                             # RCCL over xGMI: 2.8 MB per rank
+            tl_all = torch.cat(gathered, 0)
+        else:
+            tl_all = tl
+        # this rank stitches + labels its own band of canvas rows (tiles that do not overlap the band contribute nothing)
+        lo_t = max(0, (y_lo - TILE) // STRIDE) * TILE_COLS
+        hi_t = min(len(wins), ((y_hi + STRIDE - 1) // STRIDE + 1) * TILE_COLS)
+        w_band = win_all[lo_t:hi_t].clone()
+        w_band[:, 0:2] -= y_lo
+        canvas = ops.stitch(tl_all[lo_t:hi_t], w_band, up, (t, l), (y_hi - y_lo, W))
+        probs, labels = pipe.postprocess(canvas, want_probs=False)
+        return labels
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    check(lib.sg_profile_enable(1 << 16))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.sg_profile_disable()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    def prof(cat):
+        ms, fl, n, dr = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
+        lib.sg_profile_read(cat, C.byref(ms), C.byref(fl), C.byref(n), C.byref(dr))
+        return ms.value, fl.value, n.value, dr.value
+
+    tiles_total = len(wins) * args.steps
+    value = tiles_total * TILE * TILE / dt / 1e6
+    if rank == 0:
+        g_ms, g_fl, g_n, g_drop = prof(0)
+        a_ms, a_fl, a_n, _ = prof(1)
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        out = {
+            "metric": "segmented Mpix/sec ViT-L/14 512-tile slide", "value": round(value, 3), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "ViT-L/14, 512x512x3 uint8 tiles at stride 256 (padded to 518, N=1370 tokens), "
+                                   "model_type=Experimental + similarity enhancement + outlier suppression k=30 + global debias 0.2, "
+                                   "8 Potsdam queries / 6 classes, slide stitch + arg-max labels",
+                       "tiles_per_step_per_gpu": TILE_ROWS_PER_RANK * TILE_COLS, "tiles_per_launch": args.tiles_per_launch,
+                       "scene": f"{H}x{W}", "partition": f"tile rows over {world} rank(s), all-gather of patch-grid logits"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": g_n, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
+                         "algorithmic_gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3), "events_dropped": g_drop,
+                         "attention": {"kernel": "attn_kernel", "achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else 0.0,
+                                       "launches": a_n, "avg_launch_us": round(a_ms * 1e3 / max(a_n, 1), 2)},
+                         "share_of_step_time": {"gemm_bf16": round(g_ms / (dt * 1e3), 4), "attention": round(a_ms / (dt * 1e3), 4)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libsegearth_hip call failed")
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,9 @@ P, I, F, Z, L = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "sg_last_error": (C.c_char_p, []),
     "sg_version": (I, []),
+    "sg_profile_enable": (I, [I]),
+    "sg_profile_disable": (I, []),
+    "sg_profile_read": (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(L), C.POINTER(L)]),
     "sg_create": (I, [C.POINTER(P), I, C.POINTER(VitDesc)]),
     "sg_destroy": (None, [P]),
     "sg_vit_set_tensor": (I, [P, C.c_char_p, P, L, P]),
@@ -71,6 +74,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch owns device memory and streams, so the library must bind to the SAME HIP runtime instance:
+    # import torch first (its bundled libamdhip64 is then the one already loaded when ours resolves).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "

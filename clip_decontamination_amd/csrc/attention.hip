@@ -24,74 +24,112 @@ typedef __attribute__((address_space(3))) short4_* lds_s4_ptr;
 template <int DH> struct AttnCfg {
   static constexpr int KS = DH / 16;                 // k-steps of the score MFMA
   static constexpr int DVT = (DH + 31) / 32;         // 32-row tiles of O^T
-  static constexpr int K_LD = DH + 8;                // LDS row strides (elements)
-  static constexpr int V_LD = DVT * 32 + 32;
+  static constexpr int K_LD = DH + 8;                // LDS row strides (elements): conflict-free ds_read_b128 of 16 rows
+  static constexpr int V_LD = DVT * 32 + 32;         //   and 4-row ds_read_b64_tr_b16 blocks (48-dword stride at dh 64)
   static constexpr int CH = DH / 8;                  // 16-byte chunks per row
+  static constexpr int NL = (KT * CH + 255) / 256;   // chunks per thread per tile
 };
 
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// HBM -> registers (issued early, T14 async-stage split) and registers -> LDS (after the compute phase)
 template <int DH>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t st, int row0, int N, bf16_t* lds, int ld, int tid) {
-  constexpr int CH = DH / 8;
-  for (int idx = tid; idx < KT * CH; idx += 256) {
+__device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, int64_t st, int row0, int N, int tid,
+                                          u32x4 (&reg)[AttnCfg<DH>::NL]) {
+  constexpr int CH = AttnCfg<DH>::CH;
+#pragma unroll
+  for (int i = 0; i < AttnCfg<DH>::NL; ++i) {
+    int idx = tid + i * 256;
+    idx = idx < KT * CH ? idx : KT * CH - 1;           // ragged chunk counts (dh 80): load a valid duplicate, never stored
     const int r = idx / CH, c = idx % CH;
-    int gr = row0 + r; gr = gr < N ? gr : N - 1;
-    const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)gr * st + c * 8);
-    *reinterpret_cast<uint4*>(lds + r * ld + c * 8) = v;
+    int gr = row0 + r; gr = gr < N ? gr : N - 1;       // rows past the end are masked in the scores
+    reg[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)gr * st + c * 8);
+  }
+}
+template <int DH>
+__device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u32x4 (&reg)[AttnCfg<DH>::NL]) {
+  constexpr int CH = AttnCfg<DH>::CH;
+#pragma unroll
+  for (int i = 0; i < AttnCfg<DH>::NL; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < KT * CH) *reinterpret_cast<u32x4*>(lds + (idx / CH) * ld + (idx % CH) * 8) = reg[i];
   }
 }
 
-template <int DH, int TS>
+// GENERIC = additive bias and / or the 'Experimental' re-softmax (last block only); the 23 ordinary blocks run the lean path.
+// MULTI = several separately soft-maxed streams are summed (SCLIP / SegEarth / GEM); otherwise no second accumulator.
+template <int DH, int TS, bool GENERIC, bool MULTI>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* sK = reinterpret_cast<bf16_t*>(smem);                         // [TS][KT][K_LD]
-  bf16_t* sV = sK + TS * KT * C::K_LD;                                  // [KT][V_LD]
+  constexpr int BUF = TS * KT * C::K_LD + KT * C::V_LD;                 // elements per LDS buffer: [TS K tiles][V tile]
+  bf16_t* sbuf = reinterpret_cast<bf16_t*>(smem);                       // [2][BUF]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y;
   const int q_glob = blockIdx.x * QB + wave * 32 + c;
   const int q_ld = q_glob < a.N ? q_glob : a.N - 1;
   const int n = a.N - 1;
-  const float scale = a.scale_per_image ? a.scale_per_image[b] : a.scale;
+  const float scale = a.scale_per_image ? a.scale_per_image[b] : a.scale;      // > 0
+  const float c2 = scale * LOG2E;                                              // scores live in the exp2 domain
   const bool do_pv = a.ctx != nullptr;
-  const int n_streams = a.sum_scores ? 1 : a.n_terms;
+  const int n_streams = MULTI ? a.n_terms : 1;
   const int64_t head_off = (int64_t)b * a.sb + (int64_t)hd * DH;
-  const float lse1 = a.resoftmax ? a.lse_in[((int64_t)b * a.H + hd) * a.N + q_ld] : 0.f;
+  const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + (int64_t)hd * DH;
+  const float lse1_2 = (GENERIC && a.resoftmax) ? a.lse_in[((int64_t)b * a.H + hd) * a.N + q_ld] * LOG2E : 0.f;
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;               // transposed-read lane roles
 
-  f32x16 o_tot[C::DVT];
+  f32x16 o_tot[MULTI ? C::DVT : 1];
+  if (MULTI) {
 #pragma unroll
-  for (int t = 0; t < C::DVT; ++t)
+    for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o_tot[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) o_tot[t][r] = 0.f;
+  }
+  f32x16 o_acc[C::DVT];
   float m_run = -INFINITY, l_run = 0.f;
 
   for (int sidx = 0; sidx < n_streams; ++sidx) {
-    // Q fragments of this stream's terms (B port: lane = query, 8 consecutive k per half-wave)
-    bf16x8 qf[TS][C::KS];
+    const bf16_t* kptr[TS];
+    bf16x8 qf[TS][C::KS];                                    // B port: lane = query, 8 consecutive k per half-wave
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
+      kptr[t] = a.k[a.sum_scores ? t : sidx] + head_off;
       const bf16_t* qp = a.q[a.sum_scores ? t : sidx] + head_off + (int64_t)q_ld * a.st;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + h * 8);
     }
-    f32x16 o_acc[C::DVT];
 #pragma unroll
     for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
     m_run = -INFINITY; l_run = 0.f;
 
-    for (int k0 = 0; k0 < a.N; k0 += KT) {
-      __syncthreads();
+    u32x4 kreg[TS][C::NL], vreg[C::NL];
 #pragma unroll
-      for (int t = 0; t < TS; ++t)
-        stage_rows<DH>(a.k[a.sum_scores ? t : sidx] + head_off, a.st, k0, a.N, sK + t * KT * C::K_LD, C::K_LD, tid);
-      if (do_pv) stage_rows<DH>(a.v + (int64_t)b * a.v_sb + (int64_t)hd * DH, a.v_st, k0, a.N, sV, C::V_LD, tid);
-      __syncthreads();
+    for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, 0, a.N, tid, kreg[t]);
+    if (do_pv) load_rows<DH>(vbase, a.v_st, 0, a.N, tid, vreg);
+#pragma unroll
+    for (int t = 0; t < TS; ++t) store_rows<DH>(sbuf + t * KT * C::K_LD, C::K_LD, tid, kreg[t]);
+    if (do_pv) store_rows<DH>(sbuf + TS * KT * C::K_LD, C::V_LD, tid, vreg);
+    __syncthreads();
+    int cur = 0;
+
+    for (int k0 = 0; k0 < a.N; k0 += KT) {
+      const bool has_next = k0 + KT < a.N;
+      if (has_next) {                                        // next tile's loads fly while this tile computes
+#pragma unroll
+        for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, k0 + KT, a.N, tid, kreg[t]);
+        if (do_pv) load_rows<DH>(vbase, a.v_st, k0 + KT, a.N, tid, vreg);
+      }
+      const bf16_t* sK = sbuf + cur * BUF;
+      const bf16_t* sV = sK + TS * KT * C::K_LD;
 
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        if (k0 + sub * 32 >= a.N) break;                     // block-uniform
+        const int kb = k0 + sub * 32;
+        if (kb >= a.N) break;                                // block-uniform
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -102,41 +140,51 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], sacc, 0, 0, 0);   // S^T[key][query]
           }
-        // scores for query q_glob (lane) and keys key(r) = k0 + 32 sub + (r&3) + 8 (r>>2) + 4 h
+        // log2-domain scores for query q_glob (lane) and keys kb + (r&3) + 8 (r>>2) + 4 h
         float sc[16];
-        float mloc = -INFINITY;
+        if (GENERIC) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = sacc[r] * scale;
-          float bv = 0.f;
-          if (a.bias && key >= 1 && key < a.N && q_ld >= 1) bv = a.bias_w * a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)];
-          if (a.resoftmax) v = __expf(v - lse1) + bv; else v += bv;
-          v = key < a.N ? v : -INFINITY;
-          sc[r] = v;
-          mloc = fmaxf(mloc, v);
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float bv = 0.f;
+            if (a.bias && key >= 1 && key < a.N && q_ld >= 1) bv = a.bias_w * a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)];
+            float v = sacc[r] * c2;
+            if (a.resoftmax) v = (exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
+            sc[r] = key < a.N ? v : -INFINITY;
+          }
+        } else if (kb + 32 > a.N) {                          // tail sub-block: mask keys past the end
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = (kb + (r & 3) + 8 * (r >> 2) + 4 * h) < a.N ? sacc[r] * c2 : -INFINITY;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = sacc[r] * c2;
         }
+        float mloc = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sc[r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = exp2f(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[r] = __expf(sc[r] - m_new); lsum += sc[r]; }
+        for (int r = 0; r < 16; ++r) { sc[r] = exp2f(sc[r] - m_new); lsum += sc[r]; }
         lsum += __shfl_xor(lsum, 32, 64);
         l_run = l_run * alpha + lsum;
+        const bool grew = m_new > m_run;
         m_run = m_new;
         if (do_pv) {
+          if (__any(grew)) {                                 // wave-uniform: skip the rescale when no row maximum moved
 #pragma unroll
-          for (int t = 0; t < C::DVT; ++t)
+            for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+              for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+          }
           bf16x8 pf[2];
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)sc[8 * s2 + j];
           // V^T fragments by transposed LDS read: lane 4q+p of a 16-lane group addresses row q, cols 4p..4p+3
-          const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
           for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
@@ -151,17 +199,27 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             }
         }
       }
+      if (has_next) {                                        // the other buffer was last read one iteration ago
+        bf16_t* nK = sbuf + (cur ^ 1) * BUF;
+#pragma unroll
+        for (int t = 0; t < TS; ++t) store_rows<DH>(nK + t * KT * C::K_LD, C::K_LD, tid, kreg[t]);
+        if (do_pv) store_rows<DH>(nK + TS * KT * C::K_LD, C::V_LD, tid, vreg);
+      }
+      __syncthreads();
+      cur ^= 1;
     }
     if (do_pv) {
       const float inv = 1.0f / l_run;
 #pragma unroll
       for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_tot[t][r] += o_acc[t][r] * inv;
+        for (int r = 0; r < 16; ++r) {
+          if (MULTI) o_tot[t][r] += o_acc[t][r] * inv; else o_acc[t][r] *= inv;
+        }
     }
   }
 
-  if (a.lse_out && h == 0 && q_glob < a.N) a.lse_out[((int64_t)b * a.H + hd) * a.N + q_glob] = m_run + __logf(l_run);
+  if (a.lse_out && h == 0 && q_glob < a.N) a.lse_out[((int64_t)b * a.H + hd) * a.N + q_glob] = (m_run + log2f(l_run)) * LN2;
   if (do_pv && q_glob < a.N) {
     bf16_t* op = a.ctx + (int64_t)b * a.ctx_sb + (int64_t)q_glob * a.ctx_st + (int64_t)hd * DH;
 #pragma unroll
@@ -171,8 +229,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         const int dv = t * 32 + 8 * g4 + 4 * h;
         if (dv < DH) {
           uint2 o;
-          o.x = pack_bf2(o_tot[t][4 * g4 + 0] * a.out_scale, o_tot[t][4 * g4 + 1] * a.out_scale);
-          o.y = pack_bf2(o_tot[t][4 * g4 + 2] * a.out_scale, o_tot[t][4 * g4 + 3] * a.out_scale);
+          const f32x16& of = MULTI ? o_tot[t] : o_acc[t];
+          o.x = pack_bf2(of[4 * g4 + 0] * a.out_scale, of[4 * g4 + 1] * a.out_scale);
+          o.y = pack_bf2(of[4 * g4 + 2] * a.out_scale, of[4 * g4 + 3] * a.out_scale);
           *reinterpret_cast<uint2*>(op + dv) = o;
         }
       }
@@ -182,11 +241,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 template <int DH, int TS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<DH>;
-  const size_t lds = (size_t)(TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
-  auto kern = attn_kernel<DH, TS>;
+  const size_t lds = (size_t)2 * (TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
+  const bool generic = a.bias != nullptr || a.resoftmax != 0;
+  const bool multi = !a.sum_scores && a.n_terms > 1;
+  auto kern = generic ? (multi ? attn_kernel<DH, TS, true, true> : attn_kernel<DH, TS, true, false>)
+                      : (multi ? attn_kernel<DH, TS, false, true> : attn_kernel<DH, TS, false, false>);
   if (lds > 64 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)cdiv(a.N, QB), (unsigned)a.H, (unsigned)a.B);
+  // algorithmic FLOPs: 2*N*N*dh per (term score) + 2*N*N*dh per stream PV, per (image, head)
+  const int streams = a.sum_scores ? 1 : a.n_terms;
+  const double fl = (double)a.B * a.H * 2.0 * a.N * (double)a.N * DH * (a.n_terms + (a.ctx ? streams : 0));
+  prof_begin(PROF_ATTENTION, fl, s);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  prof_end(PROF_ATTENTION, s);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

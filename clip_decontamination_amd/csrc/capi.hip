@@ -17,6 +17,29 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ---- live kernel timing ------------------------------------------------------------------------------------
+struct ProfState {
+  bool on = false;
+  int cap = 0;
+  std::vector<hipEvent_t> start[PROF_NCAT], stop[PROF_NCAT];
+  int used[PROF_NCAT] = {0, 0, 0};
+  double work[PROF_NCAT] = {0, 0, 0};
+  int64_t dropped[PROF_NCAT] = {0, 0, 0};
+};
+static ProfState g_prof;
+bool prof_on() { return g_prof.on; }
+void prof_begin(int cat, double work, hipStream_t s) {
+  if (!g_prof.on) return;
+  if (g_prof.used[cat] >= g_prof.cap) { g_prof.dropped[cat]++; return; }
+  g_prof.work[cat] += work;
+  (void)hipEventRecord(g_prof.start[cat][g_prof.used[cat]], s);
+}
+void prof_end(int cat, hipStream_t s) {
+  if (!g_prof.on || g_prof.used[cat] >= g_prof.cap) return;
+  (void)hipEventRecord(g_prof.stop[cat][g_prof.used[cat]], s);
+  g_prof.used[cat]++;
+}
+
 // ---- a bump allocator over caller-provided (or arena) memory ------------------------------------------------
 struct Bump {
   char* base; size_t off, cap; bool dry;
@@ -260,6 +283,35 @@ static int find_layer_tensor(const char* rest, int& slot) {
 
 extern "C" const char* sg_last_error(void) { return g_err; }
 extern "C" int sg_version(void) { return 100; }
+
+// Live timing for bench.py: HIP events bracket every launch of a kernel family on the stream it is launched on.
+extern "C" int sg_profile_enable(int capacity) {
+  SG_REQUIRE(capacity > 0 && capacity <= (1 << 20), "sg_profile_enable: bad capacity");
+  if (capacity > g_prof.cap) {
+    for (int c = 0; c < PROF_NCAT; ++c) {
+      g_prof.start[c].resize(capacity); g_prof.stop[c].resize(capacity);
+      for (int i = g_prof.cap; i < capacity; ++i) { SG_HIP(hipEventCreate(&g_prof.start[c][i])); SG_HIP(hipEventCreate(&g_prof.stop[c][i])); }
+    }
+    g_prof.cap = capacity;
+  }
+  for (int c = 0; c < PROF_NCAT; ++c) { g_prof.used[c] = 0; g_prof.work[c] = 0; g_prof.dropped[c] = 0; }
+  g_prof.on = true;
+  return SG_OK;
+}
+extern "C" int sg_profile_disable(void) { g_prof.on = false; return SG_OK; }
+// category: 0 bf16 GEMM, 1 fused attention, 2 f32 GEMM.  Call after the stream has been synchronised.
+extern "C" int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped) {
+  SG_REQUIRE(category >= 0 && category < PROF_NCAT && total_ms && total_flops && launches, "sg_profile_read: bad argument");
+  double ms = 0;
+  for (int i = 0; i < g_prof.used[category]; ++i) {
+    float t = 0.f;
+    SG_HIP(hipEventElapsedTime(&t, g_prof.start[category][i], g_prof.stop[category][i]));
+    ms += t;
+  }
+  *total_ms = ms; *total_flops = g_prof.work[category]; *launches = g_prof.used[category];
+  if (dropped) *dropped = g_prof.dropped[category];
+  return SG_OK;
+}
 
 extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) {
   SG_REQUIRE(out && desc, "sg_create: null argument");

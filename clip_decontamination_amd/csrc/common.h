@@ -85,6 +85,12 @@ __device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + e
 
 enum Act { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
 
+// ---- optional live kernel timing (bench.py roofline): HIP events around the launches of one kernel family ----
+enum ProfCat { PROF_GEMM_BF16 = 0, PROF_ATTENTION = 1, PROF_GEMM_F32 = 2, PROF_NCAT = 3 };
+bool prof_on();
+void prof_begin(int cat, double work, hipStream_t s);   // work = algorithmic FLOPs of the launch
+void prof_end(int cat, hipStream_t s);
+
 // ---- internal op entry points (defined across the .hip files) -------------------------------------
 // bf16 GEMM: C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual).  A, W bf16 (K contiguous, K % 64 == 0).
 struct GemmBf16Args {

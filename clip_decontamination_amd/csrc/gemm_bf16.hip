@@ -163,6 +163,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   dim3 grid((unsigned)tiles, (unsigned)a.batch);
+  prof_begin(PROF_GEMM_BF16, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
   switch (a.act * 2 + (a.c_is_bf16 ? 1 : 0)) {
     case 0: launch<ACT_NONE, false>(a, vec, grid, s); break;
     case 1: launch<ACT_NONE, true>(a, vec, grid, s); break;
@@ -172,6 +173,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
     case 5: launch<ACT_GELU, true>(a, vec, grid, s); break;
     default: return fail(SG_ERR_INVALID, "gemm_bf16: bad act %d", a.act);
   }
+  prof_end(PROF_GEMM_BF16, s);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

@@ -106,7 +106,9 @@ int gemm_f32(const GemmF32Args& a, hipStream_t s) {
   SG_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0 && a.inner > 0, "gemm_f32: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   const int64_t tiles = cdiv(a.M, FM) * cdiv(a.N, FN);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_f32: grid too large");
+  prof_begin(PROF_GEMM_F32, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles, (unsigned)a.batch), dim3(256), 0, s, a);
+  prof_end(PROF_GEMM_F32, s);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

@@ -1,0 +1,154 @@
+"""Sliding-window segmentation pipeline on top of the HIP library (host logic only).
+
+Mirrors reference segmentor.py: ``forward_feature`` (:286-392), ``forward_slide`` (:394-451),
+``postprocess_result`` (:475-499) -- but tiles are cropped / padded / embedded on the device in batches,
+stitched write-once, and (optionally) partitioned over the ranks of a torch.distributed group with ONE
+all-gather of the per-tile patch-grid logit maps.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .engine import HipCLIP, compute_padsize
+
+
+def tile_windows(H: int, W: int, stride: Tuple[int, int], crop: Tuple[int, int]) -> List[Tuple[int, int, int, int]]:
+    """Raster-order windows (y1, y2, x1, x2); the last window of each axis is shifted back inside the
+    image (reference segmentor.py:411-423)."""
+    hs, ws = stride
+    hc, wc = crop
+    hg = max(H - hc + hs - 1, 0) // hs + 1
+    wg = max(W - wc + ws - 1, 0) // ws + 1
+    out = []
+    for hi in range(hg):
+        for wi in range(wg):
+            y2 = min(hi * hs + hc, H)
+            x2 = min(wi * ws + wc, W)
+            out.append((max(y2 - hc, 0), y2, max(x2 - wc, 0), x2))
+    return out
+
+
+def partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block partition of the raster tile list: [lo, hi) for ``rank`` (sizes differ by <= 1)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class SegPipeline:
+    def __init__(self, net: HipCLIP, text: torch.Tensor, query_idx: torch.Tensor, model_type: str = "SegEarth",
+                 ignore_residual: bool = True, cls_token_lambda: float = 0.0, global_debias_factor: float = 0.0,
+                 logit_scale: float = 50.0, prob_thd: float = 0.0, bg_idx: int = 0, apply_similarity_enhancement: bool = False,
+                 upsampler=None, tiles_per_launch: int = 32):
+        self.net = net
+        self.visual = net.visual
+        self.device = self.visual.device
+        self.text = text.to(device=self.device, dtype=torch.float32).contiguous()
+        self.query_idx = query_idx.to(device=self.device, dtype=torch.int32).contiguous()
+        self.num_queries = int(self.text.shape[0])
+        self.num_classes = int(query_idx.max()) + 1
+        self.model_type = model_type
+        self.ignore_residual = ignore_residual
+        self.cls_token_lambda = float(cls_token_lambda)
+        self.global_debias_factor = float(global_debias_factor)
+        self.logit_scale, self.prob_thd, self.bg_idx = float(logit_scale), float(prob_thd), int(bg_idx)
+        self.apply_similarity_enhancement = apply_similarity_enhancement
+        self.upsampler = upsampler
+        self.tiles_per_launch = int(tiles_per_launch)
+
+    # -- per-tile logits -----------------------------------------------------------------------------------
+    def tile_logits(self, scene: torch.Tensor, windows: Sequence[Tuple[int, int, int, int]], tile_hw: Tuple[int, int],
+                    scene_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> [T, Q, gh, gw] patch-grid logits (or [T, Q, H', W'] per-pixel logits with the JBU upsampler)."""
+        v = self.visual
+        P = v.cfg.patch
+        th, tw = tile_hw
+        l, r, t, b = compute_padsize(th, tw, P)
+        gh, gw = (th + t + b) // P, (tw + l + r) // P
+        opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement)
+        win = torch.tensor(list(windows), dtype=torch.int32, device=self.device).reshape(-1, 4)
+        outs = []
+        for i in range(0, win.shape[0], self.tiles_per_launch):
+            w = win[i:i + self.tiles_per_launch]
+            si = None if scene_index is None else scene_index[i:i + self.tiles_per_launch]
+            cls, tok = v.forward_tiles(scene, w, tile_hw, opts, si)
+            if self.upsampler is not None:
+                outs.append(self.upsampler.logits(tok, cls, scene, w, tile_hw, (l, t), (gh, gw), self.text,
+                                                  self.global_debias_factor, self.cls_token_lambda, si))
+            else:
+                lg = ops.cosine_logits(tok, cls, self.text, self.global_debias_factor if cls is not None else 0.0,
+                                       self.cls_token_lambda if cls is not None else 0.0)
+                outs.append(lg.reshape(w.shape[0], self.num_queries, gh, gw))
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+    # -- reference forward_slide -----------------------------------------------------------------------------
+    def forward_slide(self, scene: torch.Tensor, stride, crop, ori_shape=None, group=None) -> torch.Tensor:
+        """scene: f32 [3,H,W] normalised planes or u8 [H,W,3].  Returns logits [1,Q,H_ori,W_ori]."""
+        if scene.dtype == torch.uint8:
+            H, W = int(scene.shape[0]), int(scene.shape[1])
+        else:
+            H, W = int(scene.shape[-2]), int(scene.shape[-1])
+        stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
+        crop = (crop, crop) if isinstance(crop, int) else tuple(crop)
+        wins = tile_windows(H, W, stride, crop)
+        tile_hw = (wins[0][1] - wins[0][0], wins[0][3] - wins[0][2])
+        P = self.visual.cfg.patch
+        l, r, t, b = compute_padsize(tile_hw[0], tile_hw[1], P)
+        up_hw = (tile_hw[0] + t + b, tile_hw[1] + l + r)
+        world, rank = 1, 0
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+        if world == 1:
+            tl = self.tile_logits(scene, wins, tile_hw)
+        else:
+            tl = self.gather_tile_logits(scene, wins, tile_hw, world, rank, group)
+        win_dev = torch.tensor(wins, dtype=torch.int32, device=self.device)
+        if self.upsampler is not None:
+            up_hw_src = up_hw           # per-pixel logits: the bilinear resize inside stitch is the identity
+            canvas = ops.stitch(tl, win_dev, up_hw_src, (t, l), (H, W))
+        else:
+            canvas = ops.stitch(tl, win_dev, up_hw, (t, l), (H, W))
+        if ori_shape is not None and tuple(ori_shape) != (H, W):
+            canvas = ops.resize_bilinear(canvas, tuple(ori_shape))
+        return canvas.unsqueeze(0)
+
+    def gather_tile_logits(self, scene, wins, tile_hw, world, rank, group=None) -> torch.Tensor:
+        """Rank r computes a contiguous block of the raster tile list; one all-gather (RCCL over xGMI on GPUs)
+        of equal-sized [T_pad, Q, gh, gw] blocks rebuilds the full list on every rank."""
+        T = len(wins)
+        lo, hi = partition(T, world, rank)
+        t_pad = (T + world - 1) // world
+        mine = list(wins[lo:hi])
+        if not mine:                                   # more ranks than tiles: compute a dummy so shapes agree
+            mine = [wins[0]]
+        local = self.tile_logits(scene, mine, tile_hw)
+        block = local.new_zeros((t_pad,) + tuple(local.shape[1:]))
+        block[:hi - lo] = local[:hi - lo]
+        gathered = [torch.empty_like(block) for _ in range(world)]
+        torch.distributed.all_gather(gathered, block, group=group)
+        parts = []
+        for r in range(world):
+            a, b = partition(T, world, r)
+            parts.append(gathered[r][:b - a])
+        return torch.cat(parts, 0)
+
+    # -- reference forward_feature (whole image / explicit logit size) ------------------------------------------
+    def forward_feature(self, img: torch.Tensor, logit_size=None) -> torch.Tensor:
+        """img [B,3,H,W] (H, W already patch multiples or not -- no padding is applied here, as in the
+        reference) -> [B,Q,h,w] bilinearly resized to ``logit_size`` (default: the image size)."""
+        B, _, H, W = img.shape
+        P = self.visual.cfg.patch
+        Hc, Wc = (H // P) * P, (W // P) * P           # conv1 (stride P) ignores a ragged remainder
+        wins = [(0, Hc, 0, Wc)] * B
+        idx = torch.arange(B, dtype=torch.int32, device=self.device)
+        tl = self.tile_logits(img, wins, (Hc, Wc), idx)
+        size = (H, W) if logit_size is None else tuple(logit_size)
+        return torch.stack([ops.resize_bilinear(tl[i], size) for i in range(B)], 0)
+
+    # -- reference postprocess_result --------------------------------------------------------------------------
+    def postprocess(self, seg_logits: torch.Tensor, want_probs: bool = True):
+        """seg_logits [Q,H,W] -> (probs [K,H,W], labels int64 [1,H,W])."""
+        return ops.postprocess(seg_logits, self.query_idx, self.num_classes, self.logit_scale, self.prob_thd, self.bg_idx, want_probs)

@@ -105,6 +105,13 @@ typedef struct sg_tile_batch {
 const char* sg_last_error(void);
 int sg_version(void);
 
+/* ---- live kernel timing (measurement only; used by bench.py's roofline) -------------------------
+ * HIP events bracket every launch of a kernel family on the stream it is launched on.
+ * category: 0 = bf16 MFMA GEMM, 1 = fused attention, 2 = f32 MFMA GEMM.  Read after synchronising. */
+int sg_profile_enable(int capacity);
+int sg_profile_disable(void);
+int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped);
+
 /* ---- context and weights ------------------------------------------------------------------
  * sg_create replaces create_model(...) + .eval().to(device) (segmentor.py:69-131) for the
  * vision tower only; weights arrive by their visual.* state-dict names
