@@ -64,6 +64,13 @@ SIGNATURES = {
     "sg_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
     "sg_op_attention": (I, [P, I, I, I, I, I, P, F, P, P, P, I, P, Z, P]),
     "sg_adaptive_conv": (I, [P, P, I, I, I, I, I, P, P]),
+    "sg_jbu_create": (I, [C.POINTER(P), I, I, I]),
+    "sg_jbu_destroy": (None, [P]),
+    "sg_jbu_set_tensor": (I, [P, C.c_char_p, P, L, P]),
+    "sg_jbu_workspace_bytes": (Z, [P, I, I, I]),
+    "sg_jbu_upsample": (I, [P, P, P, I, I, I, I, I, I, P, P, Z, P]),
+    "sg_extract_tiles": (I, [C.POINTER(TileBatch), I, I, P, P]),
+    "sg_global_debias": (I, [P, P, I, I, I, F, P, P]),
 }
 
 _lib = None

@@ -1,7 +1,227 @@
-// SimFeatUp joint bilateral upsampler (reference simfeatup_dev/upsamplers.py:202-325).
+// SimFeatUp joint bilateral upsampler (reference simfeatup_dev/upsamplers.py:202-325) on gfx950.
+//
+// Data layout: features are pixel-major / channels-last ([B, h*w, C] f32) end to end -- the patch tokens of
+// the ViT already are -- so every tap of the adaptive convolution reads a contiguous channel vector and
+// the final 1x1 conv and the cosine logits are plain row-major GEMM / row ops.
+// One 2x stage (JBULearnedRange.forward, :253-275):
+//   guidance pool (adaptive_avg_pool2d)                       jbu_pool_kernel
+//   range_proj: conv1x1(3->32) . GELU . conv1x1(32->32)       jbu_range_proj_kernel
+//   range kernel: softmax_p(temp * <proj[window p], proj[centre]>) over the reflect-padded d x d window,
+//     * spatial gaussian, / sum.clamp(1e-7)                   jbu_kernel_kernel   (one wave per pixel, taps on lanes)
+//   fixup: K += 0.1 * conv1x1(GELU(conv1x1([K, guidance])))   two f32-MFMA GEMMs over [pixels, d^2(+3)]
+//   hr = bicubic 2x (A=-0.75, align_corners=False)            jbu_bicubic2x_kernel
+//   adaptive conv with reflect padding                        jbu_adaptive_conv_kernel (LDS-staged window + weights)
+// then  out = x + 0.1 * conv1x1_CxC(x)  (JBUOne/JBUStack.forward :301,325) as one GEMM with a residual epilogue.
+#include <string>
+#include <vector>
 #include "rowops.h"
 
 namespace sg {
+
+constexpr int KEY_DIM = 32;
+
+__device__ __forceinline__ int reflect_idx(int u, int size) {       // F.pad(mode='reflect'), pad < size
+  if (u < 0) u = -u;
+  if (u >= size) u = 2 * (size - 1) - u;
+  return u;
+}
+
+// ---- tile planes: crop + normalise + zero pad a window of the scene -> [T,3,up_h,up_w] f32 (the `img` the reference hands
+// to the upsampler, segmentor.py:371) ------------------------------------------------------------------------------------------
+__constant__ float j_mean[3] = {122.771f, 116.746f, 104.094f};
+__constant__ float j_std[3] = {68.501f, 66.632f, 70.323f};
+__global__ void extract_tiles_kernel(sg_tile_batch t, int up_h, int up_w, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)3 * up_h * up_w;
+  if (i >= per * t.n_tiles) return;
+  const int tile = (int)(i / per);
+  const int rem = (int)(i % per);
+  const int c = rem / (up_h * up_w), y = (rem / up_w) % up_h, x = rem % up_w;
+  const int ty = y - t.pad_t, tx = x - t.pad_l;
+  float v = 0.f;
+  if (ty >= 0 && ty < t.tile_h && tx >= 0 && tx < t.tile_w) {
+    const int sy = t.windows[tile * 4 + 0] + ty, sx = t.windows[tile * 4 + 2] + tx;
+    const int64_t off = t.scene_index ? (int64_t)t.scene_index[tile] * t.scene_stride : 0;
+    if (t.format == SG_IMG_F32_NCHW) v = reinterpret_cast<const float*>(t.scene)[off + ((int64_t)c * t.scene_h + sy) * t.scene_w + sx];
+    else v = ((float)reinterpret_cast<const uint8_t*>(t.scene)[off + ((int64_t)sy * t.scene_w + sx) * 3 + c] - j_mean[c]) / j_std[c];
+  }
+  out[i] = v;
+}
+
+// ---- guidance pool: F.adaptive_avg_pool2d([B,3,H,W] -> (oh,ow)), written pixel-major [B, oh*ow, 3] ------------------------
+__global__ void jbu_pool_kernel(const float* __restrict__ g, int B, int H, int W, int oh, int ow, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * oh * ow * 3) return;
+  const int c = (int)(i % 3);
+  const int ox = (int)((i / 3) % ow), oy = (int)((i / 3 / ow) % oh), b = (int)(i / 3 / ow / oh);
+  const int y0 = (int)(((int64_t)oy * H) / oh), y1 = (int)((((int64_t)oy + 1) * H + oh - 1) / oh);
+  const int x0 = (int)(((int64_t)ox * W) / ow), x1 = (int)((((int64_t)ox + 1) * W + ow - 1) / ow);
+  const float* p = g + ((int64_t)b * 3 + c) * H * W;
+  float s = 0.f;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) s += p[(int64_t)y * W + x];
+  out[i] = s / (float)((y1 - y0) * (x1 - x0));
+}
+
+// ---- range_proj (upsamplers.py:213-218): per pixel 3 -> 32 (GELU) -> 32 ---------------------------------------------------
+__global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __restrict__ gs, int64_t pixels, const float* __restrict__ w0,
+                                                             const float* __restrict__ b0, const float* __restrict__ w3,
+                                                             const float* __restrict__ b3, float* __restrict__ proj) {
+  __shared__ float sw0[KEY_DIM * 3], sb0[KEY_DIM], sw3[KEY_DIM * KEY_DIM], sb3[KEY_DIM];
+  for (int i = threadIdx.x; i < KEY_DIM * 3; i += 256) sw0[i] = w0[i];
+  for (int i = threadIdx.x; i < KEY_DIM * KEY_DIM; i += 256) sw3[i] = w3[i];
+  if (threadIdx.x < KEY_DIM) { sb0[threadIdx.x] = b0[threadIdx.x]; sb3[threadIdx.x] = b3[threadIdx.x]; }
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pixels) return;
+  const float g0 = gs[p * 3], g1 = gs[p * 3 + 1], g2 = gs[p * 3 + 2];
+  float hdn[KEY_DIM];
+#pragma unroll
+  for (int o = 0; o < KEY_DIM; ++o) hdn[o] = erf_gelu(sw0[o * 3] * g0 + sw0[o * 3 + 1] * g1 + sw0[o * 3 + 2] * g2 + sb0[o]);
+#pragma unroll 4
+  for (int o = 0; o < KEY_DIM; ++o) {
+    float a = sb3[o];
+#pragma unroll
+    for (int k = 0; k < KEY_DIM; ++k) a += sw3[o * KEY_DIM + k] * hdn[k];
+    proj[p * KEY_DIM + o] = a;
+  }
+}
+
+// ---- range * spatial kernel (upsamplers.py:230-262): one wave per pixel, the d*d taps on the lanes ---------------------------
+// X[pix][0..d2) = normalised combined kernel, X[pix][d2..d2+3) = guidance (the fixup conv's input rows).
+__global__ __launch_bounds__(256) void jbu_kernel_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int B, int H, int W,
+                                                         int r, const float* __restrict__ range_temp, const float* __restrict__ sigma,
+                                                         float* __restrict__ X) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = (int64_t)B * H * W;
+  if (pix >= total) return;
+  const int d = 2 * r + 1, d2 = d * d, ldx = d2 + 3;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H);
+  const int64_t img = (pix / W / H) * (int64_t)H * W;
+  const float temp = fminf(fmaxf(expf(range_temp[0]), 1e-4f), 1e4f);
+  const float sg = sigma[0];
+  const float step = 2.0f / (float)(d - 1);
+  float4 cq[KEY_DIM / 4];
+#pragma unroll
+  for (int k = 0; k < KEY_DIM / 4; ++k) cq[k] = *reinterpret_cast<const float4*>(proj + pix * KEY_DIM + 4 * k);
+  float val[2], sp[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = lane + 64 * s;
+    val[s] = -INFINITY; sp[s] = 0.f;
+    if (t < d2) {
+      const int i = t / d, j = t % d;
+      const int ny = reflect_idx(y + i - r, H), nx = reflect_idx(x + j - r, W);
+      const float* q = proj + (img + (int64_t)ny * W + nx) * KEY_DIM;
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < KEY_DIM / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(q + 4 * k);
+        dot += v.x * cq[k].x + v.y * cq[k].y + v.z * cq[k].z + v.w * cq[k].w;
+      }
+      val[s] = temp * dot;
+      const float ti = -1.0f + (float)i * step, tj = -1.0f + (float)j * step;
+      sp[s] = expf(-(ti * ti + tj * tj) / (2.0f * sg * sg));
+    }
+  }
+  const float mx = wave_max(fmaxf(val[0], val[1]));
+  float e0 = expf(val[0] - mx), e1 = expf(val[1] - mx);          // exp(-inf) = 0 for the unused lanes
+  const float inv = 1.0f / wave_sum(e0 + e1);
+  e0 = e0 * inv * sp[0]; e1 = e1 * inv * sp[1];
+  const float nrm = fmaxf(wave_sum(e0 + e1), 1e-7f);
+  float* xr = X + pix * ldx;
+  if (lane < d2) xr[lane] = e0 / nrm;
+  if (lane + 64 < d2) xr[lane + 64] = e1 / nrm;
+  if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
+}
+
+// ---- bicubic 2x (torch.nn.Upsample(size, mode='bicubic', align_corners=False), A = -0.75) on [B,h,w,C] -> [B,oh,ow,C] ----------
+__device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__device__ __forceinline__ void cubic_taps(int dst, int in, int out, int* idx, float* w) {
+  const float A = -0.75f;
+  const float src = ((float)in / (float)out) * ((float)dst + 0.5f) - 0.5f;
+  const float fl = floorf(src);
+  const float t = src - fl;
+  const int i0 = (int)fl;
+  w[0] = cc2(t + 1.f, A); w[1] = cc1(t, A); w[2] = cc1(1.f - t, A); w[3] = cc2(2.f - t, A);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int j = i0 - 1 + k; idx[k] = j < 0 ? 0 : (j > in - 1 ? in - 1 : j); }
+}
+__global__ __launch_bounds__(256) void jbu_bicubic_kernel(const float* __restrict__ src, int B, int h, int w, int C, int oh, int ow,
+                                                          float* __restrict__ dst) {
+  const int C4 = C >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * oh * ow * C4) return;
+  const int c4 = (int)(i % C4);
+  const int ox = (int)((i / C4) % ow), oy = (int)((i / C4 / ow) % oh), b = (int)(i / C4 / ow / oh);
+  int iy[4], ix[4]; float wy[4], wx[4];
+  cubic_taps(oy, h, oh, iy, wy);
+  cubic_taps(ox, w, ow, ix, wx);
+  const float* base = src + (int64_t)b * h * w * C + 4 * c4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(base + ((int64_t)iy[a] * w + ix[k]) * C);
+      row.x += wx[k] * v.x; row.y += wx[k] * v.y; row.z += wx[k] * v.z; row.w += wx[k] * v.w;
+    }
+    acc.x += wy[a] * row.x; acc.y += wy[a] * row.y; acc.z += wy[a] * row.z; acc.w += wy[a] * row.w;
+  }
+  *reinterpret_cast<float4*>(dst + ((int64_t)(b * oh + oy) * ow + ox) * C + 4 * c4) = acc;
+}
+
+// ---- adaptive convolution, channels-last, reflect padding folded into the window staging ---------------------------------------
+// Workgroup = 8x8 output pixels x 32 channels.  LDS holds the (8+2r)^2 reflect-indexed window of those 32 channels (row stride
+// 36 floats: conflict-free 16-byte reads across a row of pixels) and the 64 pixels' d*d weights (tap-major).
+constexpr int AC_T = 8, AC_CC = 32, AC_LD = 36;
+__global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const float* __restrict__ hr, const float* __restrict__ Kf, int H, int W,
+                                                                int C, int r, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int d = 2 * r + 1, d2 = d * d, WT = AC_T + 2 * r;
+  float* sWin = sm;                                  // [WT*WT][AC_LD]
+  float* sKw = sm + WT * WT * AC_LD;                 // [d2][64]
+  const int tiles_x = (W + AC_T - 1) / AC_T;
+  const int ty0 = (blockIdx.x / tiles_x) * AC_T, tx0 = (blockIdx.x % tiles_x) * AC_T;
+  const int c0 = blockIdx.y * AC_CC, b = blockIdx.z, tid = threadIdx.x;
+  const float* hb = hr + (int64_t)b * H * W * C;
+  for (int i = tid; i < WT * WT * (AC_CC / 4); i += 256) {
+    const int pos = i / (AC_CC / 4), q = i % (AC_CC / 4);
+    const int wy = pos / WT, wx = pos % WT;
+    int sy = ty0 + wy - r, sx = tx0 + wx - r;
+    sy = sy > H - 1 + r ? H - 1 + r : sy; sx = sx > W - 1 + r ? W - 1 + r : sx;      // ragged last tile: stay inside the padded image
+    sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 + 4 * q < C) v = *reinterpret_cast<const float4*>(hb + ((int64_t)sy * W + sx) * C + c0 + 4 * q);
+    *reinterpret_cast<float4*>(sWin + pos * AC_LD + 4 * q) = v;
+  }
+  for (int i = tid; i < d2 * 64; i += 256) {
+    const int pxl = i / d2, t = i % d2;                                              // coalesced along the taps of one pixel
+    int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+    y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+    sKw[t * 64 + pxl] = Kf[(((int64_t)b * H + y) * W + x) * d2 + t];
+  }
+  __syncthreads();
+  const int pxl = tid & 63, cg = tid >> 6, py = pxl >> 3, px = pxl & 7;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j) {
+      const float wv = sKw[(i * d + j) * 64 + pxl];
+      const float* p = sWin + ((py + i) * WT + (px + j)) * AC_LD + cg * 8;
+      const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+      a0.x += wv * v0.x; a0.y += wv * v0.y; a0.z += wv * v0.z; a0.w += wv * v0.w;
+      a1.x += wv * v1.x; a1.y += wv * v1.y; a1.z += wv * v1.z; a1.w += wv * v1.w;
+    }
+  const int y = ty0 + py, x = tx0 + px, c = c0 + cg * 8;
+  if (y < H && x < W) {
+    float* o = out + (((int64_t)b * H + y) * W + x) * C + c;
+    if (c < C) *reinterpret_cast<float4*>(o) = a0;
+    if (c + 4 < C) *reinterpret_cast<float4*>(o + 4) = a1;
+  }
+}
 
 // Stand-alone adaptive convolution in FeatUp's NCHW calling convention
 // (featup.adaptive_conv_cuda.AdaptiveConv.apply as used at upsamplers.py:274; semantics restated from
@@ -21,9 +241,248 @@ __global__ __launch_bounds__(256) void adaptive_conv_nchw_kernel(const float* __
   out[((int64_t)(b * C + c) * h + y) * w + x] = acc;
 }
 
+// tokens' = tokens - cls_hat * (cos(tokens, cls_hat) * factor)   (segmentor.py:322-336), cls_hat = cls / ||cls||
+__global__ __launch_bounds__(256) void global_debias_kernel(const float* __restrict__ tokens, const float* __restrict__ cls, int n, int E,
+                                                            float factor, float* __restrict__ out) {
+  __shared__ float s_inv;
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cr = cls + (int64_t)b * E;
+  if (wave == 0) {
+    float ss = 0.f;
+    for (int i = lane; i < E; i += 64) ss += cr[i] * cr[i];
+    ss = wave_sum(ss);
+    if (lane == 0) s_inv = 1.0f / sqrtf(ss);
+  }
+  __syncthreads();
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= n) return;
+  const float ci = s_inv;
+  const float* f = tokens + ((int64_t)b * n + t) * E;
+  float ff = 0.f, fc = 0.f, cc = 0.f;
+  for (int i = lane; i < E; i += 64) { const float x = f[i], c = cr[i] * ci; ff += x * x; fc += x * c; cc += c * c; }
+  ff = wave_sum(ff); fc = wave_sum(fc); cc = wave_sum(cc);
+  const float w = (fc / (sqrtf(ff) * sqrtf(cc))) * factor;
+  float* o = out + ((int64_t)b * n + t) * E;
+  for (int i = lane; i < E; i += 64) o[i] = f[i] - cr[i] * ci * w;
+}
+
+struct JbuStage {
+  int r;
+  float *range_temp, *sigma, *rp0_w, *rp0_b, *rp3_w, *rp3_b, *fx0_w, *fx0_b, *fx3_w, *fx3_b;
+};
+
 }  // namespace sg
 
 using namespace sg;
+
+struct sg_jbu {
+  int device, kind, C, n_stage_sets;
+  void* arena; size_t arena_bytes;
+  JbuStage st[4];
+  float *fin_w, *fin_b;
+  void* fin_w16;
+  std::vector<uint8_t> have;
+};
+
+namespace sg {
+static const char* kStageTensor[10] = {"range_temp", "sigma_spatial", "range_proj.0.weight", "range_proj.0.bias", "range_proj.3.weight",
+                                       "range_proj.3.bias", "fixup_proj.0.weight", "fixup_proj.0.bias", "fixup_proj.3.weight",
+                                       "fixup_proj.3.bias"};
+static int64_t stage_numel(int slot, int r) {
+  const int64_t d2 = (int64_t)(2 * r + 1) * (2 * r + 1);
+  switch (slot) {
+    case 0: case 1: return 1;
+    case 2: return KEY_DIM * 3; case 3: return KEY_DIM; case 4: return KEY_DIM * KEY_DIM; case 5: return KEY_DIM;
+    case 6: return d2 * (d2 + 3); case 7: return d2; case 8: return d2 * d2; default: return d2;
+  }
+}
+__global__ void scale_kernel(float* p, float a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] *= a;
+}
+}  // namespace sg
+
+extern "C" int sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim) {
+  SG_REQUIRE(out && (kind == 0 || kind == 1) && feat_dim > 0 && feat_dim % 4 == 0, "sg_jbu_create: bad arguments (kind 0 = jbu_one, 1 = jbu_stack; feat_dim %% 4 == 0)");
+  SG_HIP(hipSetDevice(device));
+  sg_jbu* j = new sg_jbu();
+  j->device = device; j->kind = kind; j->C = feat_dim; j->n_stage_sets = kind == 0 ? 1 : 4;
+  const int r = kind == 0 ? 5 : 3;                     // JBUOne radius 5, JBUStack radius 3 (upsamplers.py:281-284,308)
+  size_t bytes = 0;
+  auto lay = [&](char* base) {
+    size_t off = 0;
+    auto take = [&](size_t n) { off = align_up(off, 256); void* p = base ? base + off : nullptr; off += n; return p; };
+    for (int s = 0; s < j->n_stage_sets; ++s) {
+      JbuStage& S = j->st[s]; S.r = r;
+      float** slots[10] = {&S.range_temp, &S.sigma, &S.rp0_w, &S.rp0_b, &S.rp3_w, &S.rp3_b, &S.fx0_w, &S.fx0_b, &S.fx3_w, &S.fx3_b};
+      for (int t = 0; t < 10; ++t) *slots[t] = (float*)take((size_t)stage_numel(t, r) * 4);
+    }
+    j->fin_w = (float*)take((size_t)feat_dim * feat_dim * 4);
+    j->fin_b = (float*)take((size_t)feat_dim * 4);
+    j->fin_w16 = take((size_t)feat_dim * feat_dim * 2);
+    bytes = align_up(off, 256);
+  };
+  lay(nullptr);
+  j->arena_bytes = bytes;
+  hipError_t e = hipMalloc(&j->arena, bytes);
+  if (e != hipSuccess) { delete j; return fail(SG_ERR_HIP, "sg_jbu_create: hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e)); }
+  lay((char*)j->arena);
+  j->have.assign(j->n_stage_sets * 10 + 2, 0);
+  *out = j;
+  return SG_OK;
+}
+
+extern "C" void sg_jbu_destroy(sg_jbu* j) {
+  if (!j) return;
+  if (j->arena) (void)hipFree(j->arena);
+  delete j;
+}
+
+extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, int64_t numel, sg_stream st) {
+  SG_REQUIRE(j && name && src, "sg_jbu_set_tensor: null argument");
+  hipStream_t s = as_stream(st);
+  auto put = [&](float* dst, int64_t n) -> int {
+    SG_REQUIRE(numel == n, "sg_jbu_set_tensor(%s): expected %lld elements, got %lld", name, (long long)n, (long long)numel);
+    SG_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return SG_OK;
+  };
+  if (!strcmp(name, "fixup_proj.1.weight")) {
+    SG_TRY(put(j->fin_w, (int64_t)j->C * j->C));
+    if (j->C % 64 == 0) SG_TRY(pack_rows(src, j->C, j->C, j->C, j->fin_w16, j->C, 1, s));
+    j->have[j->n_stage_sets * 10] = 1; return SG_OK;
+  }
+  if (!strcmp(name, "fixup_proj.1.bias")) {
+    SG_TRY(put(j->fin_b, j->C));
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)cdiv(j->C, 256)), dim3(256), 0, s, j->fin_b, 0.1f, (int64_t)j->C);   // epilogue is alpha*acc + bias
+    SG_LAUNCH_CHECK();
+    j->have[j->n_stage_sets * 10 + 1] = 1; return SG_OK;
+  }
+  int set = -1; const char* rest = nullptr;
+  if (j->kind == 0 && !strncmp(name, "up.", 3)) { set = 0; rest = name + 3; }
+  else if (j->kind == 1 && !strncmp(name, "up", 2) && name[2] >= '1' && name[2] <= '4' && name[3] == '.') { set = name[2] - '1'; rest = name + 4; }
+  if (set >= 0) {
+    for (int t = 0; t < 10; ++t)
+      if (!strcmp(rest, kStageTensor[t])) {
+        JbuStage& S = j->st[set];
+        float* slots[10] = {S.range_temp, S.sigma, S.rp0_w, S.rp0_b, S.rp3_w, S.rp3_b, S.fx0_w, S.fx0_b, S.fx3_w, S.fx3_b};
+        SG_TRY(put(slots[t], stage_numel(t, S.r)));
+        if (t == 9) {                                  // K += 0.1 * (H.W3^T + b3): the GEMM epilogue computes 0.1*acc + bias
+          hipLaunchKernelGGL(scale_kernel, dim3((unsigned)cdiv(numel, 256)), dim3(256), 0, s, slots[t], 0.1f, numel);
+          SG_LAUNCH_CHECK();
+        }
+        j->have[set * 10 + t] = 1;
+        return SG_OK;
+      }
+  }
+  return fail(SG_ERR_INVALID, "sg_jbu_set_tensor: unknown tensor name '%s' for this upsampler kind", name);
+}
+
+namespace sg {
+struct JbuPlan { float *gs, *proj, *X, *H1, *Kf, *hr, *bufA, *bufB; void* x16; };
+static size_t jbu_plan(const sg_jbu* j, int B, int gh, int gw, void* ws, bool dry, JbuPlan& p) {
+  const int r = j->st[0].r, d2 = (2 * r + 1) * (2 * r + 1);
+  const int64_t pixels = (int64_t)B * 16 * gh * 16 * gw;              // final resolution
+  size_t off = 0;
+  auto take = [&](size_t n) { off = align_up(off, 256); void* q = dry ? nullptr : (char*)ws + off; off += n; return q; };
+  p.gs = (float*)take((size_t)pixels * 3 * 4);
+  p.proj = (float*)take((size_t)pixels * KEY_DIM * 4);
+  p.X = (float*)take((size_t)pixels * (d2 + 3) * 4);
+  p.H1 = (float*)take((size_t)pixels * d2 * 4);
+  p.Kf = (float*)take((size_t)pixels * d2 * 4);
+  p.hr = (float*)take((size_t)pixels * j->C * 4);
+  p.bufA = (float*)take((size_t)pixels / 4 * j->C * 4);                // stage-3 output (8x): ping
+  p.bufB = (float*)take((size_t)pixels * j->C * 4);                    // stage-2 / stage-4 output: pong
+  p.x16 = take((size_t)pixels * j->C * 2);
+  return align_up(off, 256);
+}
+}  // namespace sg
+
+extern "C" size_t sg_jbu_workspace_bytes(const sg_jbu* j, int B, int gh, int gw) {
+  if (!j || B <= 0 || gh <= 0 || gw <= 0) return 0;
+  JbuPlan p;
+  return jbu_plan(j, B, gh, gw, nullptr, true, p);
+}
+
+// source [B, gh*gw, C] (patch tokens), guidance [B,3,GH,GW] (the normalised, padded tile) -> out [B, (16gh*16gw), C]
+extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
+                               float* out, void* ws, size_t ws_bytes, sg_stream st) {
+  SG_REQUIRE(j && source && guidance && out && ws, "sg_jbu_upsample: null argument");
+  for (size_t i = 0; i < j->have.size(); ++i) if (!j->have[i]) return fail(SG_ERR_STATE, "sg_jbu_upsample: upsampler weights incomplete");
+  hipStream_t s = as_stream(st);
+  JbuPlan p;
+  const size_t need = jbu_plan(j, B, gh, gw, ws, false, p);
+  if (need > ws_bytes) return fail(SG_ERR_STATE, "sg_jbu_upsample: workspace %zu < required %zu", ws_bytes, need);
+  const int C = j->C;
+  const float* src = source;
+  int h = gh, w = gw;
+  for (int stg = 0; stg < 4; ++stg) {
+    const JbuStage& S = j->st[j->kind == 0 ? 0 : stg];
+    const int r = S.r, d = 2 * r + 1, d2 = d * d, oh = 2 * h, ow = 2 * w;
+    SG_REQUIRE(r < oh && r < ow, "sg_jbu_upsample: reflect padding %d needs a guidance grid larger than %dx%d", r, oh, ow);
+    SG_REQUIRE(d2 <= 128, "sg_jbu_upsample: window %d too large", d);
+    const int64_t pixels = (int64_t)B * oh * ow;
+    // ping-pong: source -> bufA (2x) -> bufB (4x) -> bufA (8x) -> bufB (16x)
+    float* dst = (stg % 2 == 0) ? p.bufA : p.bufB;
+    hipLaunchKernelGGL(jbu_pool_kernel, dim3((unsigned)cdiv(pixels * 3, 256)), dim3(256), 0, s, guidance, B, GH, GW, oh, ow, p.gs);
+    SG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(jbu_range_proj_kernel, dim3((unsigned)cdiv(pixels, 256)), dim3(256), 0, s, p.gs, pixels, S.rp0_w, S.rp0_b, S.rp3_w,
+                       S.rp3_b, p.proj);
+    SG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(jbu_kernel_kernel, dim3((unsigned)cdiv(pixels, 4)), dim3(256), 0, s, p.proj, p.gs, B, oh, ow, r, S.range_temp, S.sigma, p.X);
+    SG_LAUNCH_CHECK();
+    {  // fixup: H1 = GELU(X . W0^T + b0);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3)
+      GemmF32Args g{};
+      g.A = p.X; g.lda = d2 + 3; g.B = S.fx0_w; g.sbk = 1; g.sbn = d2 + 3; g.bias = S.fx0_b; g.C = p.H1; g.ldc = d2;
+      g.M = (int)pixels; g.N = d2; g.K = d2 + 3; g.batch = 1; g.inner = 1; g.act = ACT_GELU; g.alpha = 1.f;
+      SG_REQUIRE(pixels < (1ll << 31), "sg_jbu_upsample: too many pixels");
+      SG_TRY(gemm_f32(g, s));
+      GemmF32Args q{};
+      q.A = p.H1; q.lda = d2; q.B = S.fx3_w; q.sbk = 1; q.sbn = d2; q.bias = S.fx3_b; q.residual = p.X; q.ldr = d2 + 3; q.C = p.Kf; q.ldc = d2;
+      q.M = (int)pixels; q.N = d2; q.K = d2; q.batch = 1; q.inner = 1; q.act = ACT_NONE; q.alpha = 0.1f;
+      SG_TRY(gemm_f32(q, s));
+    }
+    hipLaunchKernelGGL(jbu_bicubic_kernel, dim3((unsigned)cdiv(pixels * (C / 4), 256)), dim3(256), 0, s, src, B, h, w, C, oh, ow, p.hr);
+    SG_LAUNCH_CHECK();
+    {
+      const int WT = AC_T + 2 * r;
+      const size_t lds = ((size_t)WT * WT * AC_LD + (size_t)d2 * 64) * sizeof(float);
+      if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jbu_adaptive_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)cdiv(C, AC_CC), (unsigned)B);
+      hipLaunchKernelGGL(jbu_adaptive_conv_kernel, grid, dim3(256), lds, s, p.hr, p.Kf, oh, ow, C, r, dst);
+      SG_LAUNCH_CHECK();
+    }
+    src = dst; h = oh; w = ow;
+  }
+  // out = x + 0.1 * (x . Wf^T + bf)     (bias pre-scaled by 0.1 at load)
+  const int64_t pixels = (int64_t)B * h * w;
+  if (precision == SG_PREC_BF16 && C % 64 == 0) {
+    SG_TRY(pack_rows(src, pixels, C, C, p.x16, C, 1, s));
+    GemmBf16Args g{};
+    g.A = (const bf16_t*)p.x16; g.lda = C; g.W = (const bf16_t*)j->fin_w16; g.ldw = C; g.bias = j->fin_b; g.residual = src; g.ldr = C;
+    g.C = out; g.ldc = C; g.c_is_bf16 = 0; g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.act = 0; g.alpha = 0.1f;
+    return gemm_bf16(g, s);
+  }
+  GemmF32Args g{};
+  g.A = src; g.lda = C; g.B = j->fin_w; g.sbk = 1; g.sbn = C; g.bias = j->fin_b; g.residual = src; g.ldr = C; g.C = out; g.ldc = C;
+  g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.inner = 1; g.act = 0; g.alpha = 0.1f;
+  return gemm_f32(g, s);
+}
+
+extern "C" int sg_extract_tiles(const sg_tile_batch* t, int up_h, int up_w, float* out, sg_stream s) {
+  SG_REQUIRE(t && out && t->scene && t->windows && t->n_tiles > 0, "sg_extract_tiles: bad arguments");
+  SG_REQUIRE(up_h >= t->tile_h + t->pad_t && up_w >= t->tile_w + t->pad_l, "sg_extract_tiles: output smaller than the padded tile");
+  const int64_t total = (int64_t)t->n_tiles * 3 * up_h * up_w;
+  hipLaunchKernelGGL(extract_tiles_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(s), *t, up_h, up_w, out);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_global_debias(const float* tokens, const float* cls, int B, int n, int E, float factor, float* out, sg_stream s) {
+  SG_REQUIRE(tokens && cls && out && B > 0 && n > 0 && E > 0 && B < 65536, "sg_global_debias: bad arguments");
+  hipLaunchKernelGGL(global_debias_kernel, dim3((unsigned)cdiv(n, 4), (unsigned)B), dim3(256), 0, as_stream(s), tokens, cls, n, E, factor, out);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
 
 extern "C" int sg_adaptive_conv(const float* input, const float* filters, int B, int C, int h, int w, int d, float* out, sg_stream s) {
   SG_REQUIRE(input && filters && out, "sg_adaptive_conv: null pointer");

@@ -77,7 +77,8 @@ class SegPipeline:
             cls, tok = v.forward_tiles(scene, w, tile_hw, opts, si)
             if self.upsampler is not None:
                 outs.append(self.upsampler.logits(tok, cls, scene, w, tile_hw, (l, t), (gh, gw), self.text,
-                                                  self.global_debias_factor, self.cls_token_lambda, si))
+                                                  self.global_debias_factor, self.cls_token_lambda, si,
+                                                  padded_hw=(th + t + b, tw + l + r)))
             else:
                 lg = ops.cosine_logits(tok, cls, self.text, self.global_debias_factor if cls is not None else 0.0,
                                        self.cls_token_lambda if cls is not None else 0.0)

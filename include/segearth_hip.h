@@ -188,6 +188,27 @@ int sg_op_attention(const float* qkv, int B, int N, int D, int H, int variant, c
  *   input [B,C,h+d-1,w+d-1], filters [B,h,w,d,d] -> out [B,C,h,w], all f32. */
 int sg_adaptive_conv(const float* input, const float* filters, int B, int C, int h, int w, int d, float* out, sg_stream s);
 
+/* JBU context.  sg_jbu_create replaces get_upsampler(name, dim) (upsamplers.py:353-369; kind 0 = 'jbu_one', 1 = 'jbu_stack');
+ * sg_jbu_set_tensor takes the tensors by their state-dict names ("up.range_temp", "up2.fixup_proj.0.weight",
+ * "fixup_proj.1.weight" ...), i.e. load_state_dict (segmentor.py:281-283);
+ * sg_jbu_upsample replaces self.upsampler(image_features, img) (segmentor.py:371 -> upsamplers.py:278-325):
+ *   source [B, gh*gw, C] patch tokens (pixel-major), guidance [B,3,GH,GW] normalised tile -> out [B, 16gh*16gw, C]. */
+typedef struct sg_jbu sg_jbu;
+int  sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim);
+void sg_jbu_destroy(sg_jbu* j);
+int  sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* dev_f32, int64_t numel, sg_stream s);
+size_t sg_jbu_workspace_bytes(const sg_jbu* j, int B, int gh, int gw);
+int  sg_jbu_upsample(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
+                     float* out, void* workspace, size_t workspace_bytes, sg_stream s);
+
+/* the normalised, zero-padded tile planes [T,3,up_h,up_w] f32 the reference hands to the upsampler as `img`
+ * (segmentor.py:424-431 crop + pad, :371) */
+int sg_extract_tiles(const sg_tile_batch* tiles, int up_h, int up_w, float* out, sg_stream s);
+
+/* similarity-weighted global debias as a stand-alone op (segmentor.py:322-336), used ahead of the upsampler:
+ *   out = tokens - cls_hat * (cos(tokens, cls_hat) * factor), tokens [B,n,E], cls [B,E] */
+int sg_global_debias(const float* tokens, const float* cls, int B, int n, int E, float factor, float* out, sg_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,3 +250,50 @@ def test_adaptive_conv(ops, golden):
     g = golden("jbu")
     out = ops.adaptive_conv(torch.from_numpy(g["ac_in"]).to(DEV), torch.from_numpy(g["ac_filt"]).to(DEV))
     assert (out.cpu() - torch.from_numpy(g["ac_out"])).abs().max().item() < 1e-5
+
+
+# ---- SimFeatUp JBU ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["jbu_one", "jbu_stack"])
+def test_jbu_matches_reference_fixture(golden, name):
+    """End-to-end upsampler against the fixture minted from the reference modules (adaptive conv = the reference's
+    in-tree torch form of FeatUp's CUDA op; third party, unpinned -- see oracle/jbu.py)."""
+    from clip_decontamination_amd import weights as Wt
+    from clip_decontamination_amd.upsampler import get_upsampler
+    g = golden("jbu")
+    src, guid = torch.from_numpy(g[f"{name}.src"]), torch.from_numpy(g[f"{name}.guidance"])
+    C = src.shape[1]
+    up = get_upsampler(name, C, DEV, "f32")
+    up.load_state_dict(Wt.make_jbu_weights(name, C, seed=3))
+    out = up(src.to(DEV), guid.to(DEV))
+    ref = torch.from_numpy(g[f"{name}.out"])
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_jbu_against_oracle_nonsquare_and_batched():
+    from clip_decontamination_amd import weights as Wt
+    from clip_decontamination_amd.upsampler import get_upsampler
+    from oracle import vit as OV
+    C, gh, gw = 32, 4, 6
+    wnp = Wt.make_jbu_weights("jbu_stack", C, seed=3)
+    src = rnd(2, C, gh, gw, seed=1)
+    guid = torch.nn.functional.interpolate(rnd(2, 3, 5, 7, seed=2), size=(16 * gh, 16 * gw), mode="bicubic") + 0.2 * rnd(2, 3, 16 * gh, 16 * gw, seed=3)
+    ref = torch.cat([OJ.jbu_forward(OV.to_torch(wnp), src[i:i + 1], guid[i:i + 1]) for i in range(2)], 0)
+    up = get_upsampler("jbu_stack", C, DEV, "f32")
+    up.load_state_dict(wnp)
+    out = up(src.to(DEV), guid.to(DEV))
+    assert (out.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_global_debias_and_extract_tiles(ops):
+    import ctypes as C
+    from clip_decontamination_amd import _lib
+    lib = _lib.load()
+    tok, cls = rnd(2, 20, 48, seed=1).to(DEV), rnd(2, 48, seed=2).to(DEV)
+    out = torch.empty_like(tok)
+    _lib.check(lib.sg_global_debias(ops.ptr(tok), ops.ptr(cls), 2, 20, 48, 0.2, ops.ptr(out), ops.stream_ptr()))
+    c = (cls / cls.norm(dim=-1, keepdim=True)).cpu()
+    t = tok.cpu()
+    sim = ((t / t.norm(dim=-1, keepdim=True)) * (c / c.norm(dim=-1, keepdim=True)).unsqueeze(1)).sum(-1)
+    ref = t - c.unsqueeze(1) * (sim.unsqueeze(-1) * 0.2)
+    assert (out.cpu() - ref).abs().max().item() < 2e-6
