@@ -45,6 +45,7 @@ SIGNATURES = {
     "sg_version": (I, []),
     "sg_profile_enable": (I, [I]),
     "sg_profile_disable": (I, []),
+    "sg_set_gemm_config": (I, [I]),
     "sg_profile_read": (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(L), C.POINTER(L)]),
     "sg_create": (I, [C.POINTER(P), I, C.POINTER(VitDesc)]),
     "sg_destroy": (None, [P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "sg_weak_token_replace": (I, [P, P, I, I, I, I, I, P, P, P]),
     "sg_similarity_map": (I, [P, L, I, I, I, I, F, I, I, P, P, Z, P]),
     "sg_op_linear": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),
+    "sg_gemm_bf16_raw": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "sg_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
     "sg_op_attention": (I, [P, I, I, I, I, I, P, F, P, P, P, I, P, Z, P]),
     "sg_adaptive_conv": (I, [P, P, I, I, I, I, I, P, P]),

@@ -298,6 +298,18 @@ extern "C" int sg_profile_enable(int capacity) {
   g_prof.on = true;
   return SG_OK;
 }
+// Raw bf16 GEMM on caller-packed operands (A [M,K], W [N,K] bf16, K % 64 == 0): C = act(A.W^T + bias) (+ residual).
+extern "C" int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
+                                int act, int c_is_bf16, sg_stream st) {
+  SG_REQUIRE(A && W && C, "sg_gemm_bf16_raw: null pointer");
+  return linear(true, A, K, W, bias, residual, C, N, !c_is_bf16, M, N, K, act, as_stream(st));
+}
+// Tuning hook for the bf16 GEMM tile configuration (-1 = automatic).
+extern "C" int sg_set_gemm_config(int cfg) {
+  if (cfg >= 100) { set_gemm_stagger(cfg - 100); return SG_OK; }       // 100 + s: start-time stagger (units of ~8k cycles x K tiles / 64)
+  set_gemm_config(cfg);
+  return SG_OK;
+}
 extern "C" int sg_profile_disable(void) { g_prof.on = false; return SG_OK; }
 // category: 0 bf16 GEMM, 1 fused attention, 2 f32 GEMM.  Call after the stream has been synchronised.
 extern "C" int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped) {

@@ -143,6 +143,450 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
   }
 }
 
+// ---- coalescing epilogue shared by the ring / ping-pong kernels ----------------------------------------------------------------
+// The MFMA fragment leaves each lane with 4 consecutive columns of one row: stored directly that is 32-byte (bf16) / 64-byte (f32)
+// pieces of 16 different rows per instruction, and the measured store rate was 1.3 TB/s.  Instead every 16-row strip of the wave's
+// tile goes through a private LDS patch (row stride TN+4 floats: conflict-free 16-byte writes) and comes back row-contiguous, so a
+// store instruction writes WHOLE 128-byte lines (8 rows x 128 B bf16, 4 rows x 256 B f32); bias / activation are applied before
+// the patch, the f32 residual is added on the way out with equally coalesced loads.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
+                                               int col0, float* patch, int lane) {
+  constexpr int TN = NI * 16, LDP = TN + 4;
+  const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
+  float4 bias4[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = col0 + j * 16 + (lane >> 4) * 4;
+    bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && n + 3 < a.N) bias4[j] = *reinterpret_cast<const float4*>(a.bias + n);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float v[4] = {acc[i][j][0] * a.alpha + bias4[j].x, acc[i][j][1] * a.alpha + bias4[j].y, acc[i][j][2] * a.alpha + bias4[j].z,
+                    acc[i][j][3] * a.alpha + bias4[j].w};
+      if (act == ACT_QUICK_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+      } else if (act == ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+      }
+      *reinterpret_cast<float4*>(patch + (lane & 15) * LDP + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const int rbase = row0 + i * 16;
+    if (c_bf16) {                                          // 8 lanes x 16 B per row, 8 rows per instruction
+      constexpr int LPR = TN / 8;                          // lanes per row
+      constexpr int RPP = 64 / LPR;                        // rows per pass
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += RPP) {
+        const int r = r0 + lane / LPR, cq = (lane % LPR) * 8;
+        const int m = rbase + r, n = col0 + cq;
+        if (r < 16 && m < a.M && n < a.N) {
+          const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
+          uint4 o; o.x = pack_bf2(x0.x, x0.y); o.y = pack_bf2(x0.z, x0.w); o.z = pack_bf2(x1.x, x1.y); o.w = pack_bf2(x1.z, x1.w);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
+        }
+      }
+    } else {                                               // 16 lanes x 16 B per row, 4 rows per instruction
+      constexpr int LPR = TN / 4;
+      constexpr int RPP = 64 / LPR;
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += RPP) {
+        const int r = r0 + lane / LPR, cq = (lane % LPR) * 4;
+        const int m = rbase + r, n = col0 + cq;
+        if (r < 16 && m < a.M && n < a.N) {
+          float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          if (res) {
+            const float4 rr = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
+            x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
+          }
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = x;
+        }
+      }
+    }
+  }
+}
+
+// ---- ring-buffered variant ---------------------------------------------------------------------------------------------
+// Same staging image, fragment reads and swapped-operand MFMAs as above, but (1) the block tile and wave grid are template
+// parameters (256x128 / 256x256 tiles with 8 waves halve the L2 bytes per FLOP), (2) the LDS is a ring of STAGES K-tiles
+// filled by global_load_lds that stay IN FLIGHT across the barrier: a counted `s_waitcnt vmcnt(N)` (never 0 in steady state)
+// retires only the tile about to be read, a raw s_barrier publishes it, and the slot freed by the previous iteration is
+// refilled immediately -- so STAGES-1 tiles of HBM/L2 latency are hidden behind the MFMA phase instead of one.
+//   iteration t:  vmcnt((STAGES-2) * G) ; s_barrier ; stage(t + STAGES - 1) ; ds_read + MFMA on slot t % STAGES
+// Slot (t-1) % STAGES is rewritten only after every wave has passed the barrier that follows its last read of it.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
+  constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int SLABS = (BM_ + BN_) / 8;                 // 1 KiB slabs (8 rows x 128 B) per K tile
+  constexpr int G = SLABS / NW;                          // global_load_lds per thread per K tile
+  constexpr int STAGE_BYTES = (BM_ + BN_) * BK * 2;
+  static_assert(SLABS % NW == 0, "slabs must divide over the waves");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WN, wave_n = wave % WN;
+  const int tiles_n = (a.N + BN_ - 1) / BN_;
+  const int tiles_m = (a.M + BM_ - 1) / BM_;
+  // XCD-aware order: consecutive ids of ONE XCD walk the n tiles of one m tile (shared A rows stay in that XCD's L2)
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  const int m0 = tile_m * BM_, n0 = tile_n * BN_;
+  const int z = blockIdx.y;
+  const bf16_t* A = a.A + (int64_t)z * a.strideA;
+  const bf16_t* W = a.W + (int64_t)z * a.strideW;
+
+  auto stage = [&](int t, int slot) {
+    char* base = lds + slot * STAGE_BYTES;
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+      const int slab = p * NW + wave;                      // wave-uniform
+      const int r = slab * 8 + (lane >> 3);                // row inside the stacked [A rows | W rows] image
+      const int c = lane & 7;
+      const int gch = c ^ ((r >> 1) & 7);
+      const bf16_t* src;
+      if (slab * 8 < BM_) { int gr = m0 + r; gr = gr < a.M ? gr : a.M - 1; src = A + (int64_t)gr * a.lda + t * BK + gch * 8; }
+      else { int gr = n0 + r - BM_; gr = gr < a.N ? gr : a.N - 1; src = W + (int64_t)gr * a.ldw + t * BK + gch * 8; }
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + slab * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = ABLATE == 4 ? 1 : a.K / BK;
+#pragma unroll
+  for (int sidx = 0; sidx < STAGES - 1; ++sidx)
+    if (sidx < nt) stage(sidx, sidx);
+
+  for (int t = 0; t < nt; ++t) {
+    const int ahead = nt - 1 - t;                          // tiles already issued beyond t
+    if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * G>();
+    else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<(STAGES >= 3 ? G : 0)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ABLATE != 1 && t + STAGES - 1 < nt) stage(t + STAGES - 1, (t + STAGES - 1) % STAGES);
+    const char* bufA = lds + (t % STAGES) * STAGE_BYTES;
+    const char* bufW = bufA + BM_ * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = kk * 4 + (lane >> 4);
+      bf16x8 fa[MI], fw[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag(bufA, wave_m * TM + i * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fw[j] = read_frag(bufW, wave_n * TN + j * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          if (ABLATE != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+          else { asm volatile("" ::"v"(fw[j]), "v"(fa[i])); }
+    }
+  }
+
+  if (ABLATE == 3) {                                       // tuning only: keep the accumulators live, store (almost) nothing
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 1234.5678f) reinterpret_cast<float*>(a.C)[0] = sum;
+    return;
+  }
+  if (vec) {                                               // N % 8 == 0, aligned: coalesced path through an LDS patch
+    __syncthreads();                                       // every wave is done reading the staging buffers
+    epilogue_store<MI, NI>(acc, a, act, c_bf16, z, m0 + wave_m * TM, n0 + wave_n * TN, reinterpret_cast<float*>(lds) + wave * 16 * (TN + 4), lane);
+    return;
+  }
+  const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wave_m * TM + i * 16 + (lane & 15);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wave_n * TN + j * 16 + (lane >> 4) * 4;
+      if (n >= a.N) continue;
+      float v[4] = {acc[i][j][0] * a.alpha, acc[i][j][1] * a.alpha, acc[i][j][2] * a.alpha, acc[i][j][3] * a.alpha};
+      if (vec) {
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (act == ACT_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        } else if (act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+        }
+        if (res) {
+          const float4 r = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+        if (c_bf16) {
+          bf16_t* C = reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
+          uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(C) = o;
+        } else {
+          float* C = reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
+          *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= a.N) break;
+          float x = v[e];
+          if (a.bias) x += a.bias[n + e];
+          if (act == ACT_QUICK_GELU) x = quick_gelu(x);
+          else if (act == ACT_GELU) x = erf_gelu(x);
+          if (res) x += res[(int64_t)m * a.ldr + n + e];
+          if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = f2bf(x);
+          else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
+        }
+      }
+    }
+  }
+}
+
+// ---- ping-pong variant: 256x256x64 tile, 8 waves = two groups of four that ALTERNATE on the matrix pipe ---------------------
+// Group g (waves 4g..4g+3, one per SIMD) owns output rows [128g, 128g+128); wave i of a group owns columns [64i, 64i+64).
+// A K tile is four phases of 16 MFMAs (one 64x32 quadrant x K=64).  Every phase is two barrier-delimited segments:
+//     READ  : ds_read_b128 of the operands the phase needs (4-12 reads) + this wave's share of the next tile's global_load_lds
+//     MFMA  : 16 x v_mfma_f32_16x16x32_bf16
+// Group 1 runs ONE barrier behind group 0, so on every SIMD one wave is in its MFMA segment while its partner reads:
+// the matrix pipe never waits for LDS latency and the LDS/TA never wait for the MFMAs.
+// LDS: 2 buffers x [A 256x64 | W 256x64] bf16 = 128 KiB, same swizzled image as above.  Hand-off rules (slot = barrier interval;
+// group 0's READ(t,p) is slot 8t+2p, group 1's is 8t+2p+1):
+//   * who loads what for tile t+1: wave (g,i) loads A rows [128g+32i,+32) in READ(t,0) and W rows [64i+32g,+32) in READ(t,1).
+//     WAR: those A rows were last read by group g in READ(t-1,2) (>= 4 slots earlier); those W rows in READ(t-1,3) of either
+//     group (slots 8t-2 / 8t-1, retired by the lgkmcnt wait that opens slots 8t-1 / 8t) -- the write is issued at slot >= 8t+2.
+//   * RAW: every wave drains its own loads (vmcnt(0)) at the end of MFMA(t,3) (slot 8t+7 / 8t+8) before the barrier; the first
+//     readers of another group's rows come >= 1 slot after that barrier (group 0 reads group-1-loaded W rows in READ(t+1,1),
+//     slot 8t+10; group 1 reads group-0-loaded W rows in READ(t+1,0), slot 8t+9).
+__global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int act, int c_bf16, int vec, int stagger) {
+  constexpr int PBM = 256, PBN = 256;
+  constexpr int BUF_BYTES = (PBM + PBN) * BK * 2;          // 64 KiB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wi = wave & 3;
+  const int tiles_n = (a.N + PBN - 1) / PBN, tiles_m = (a.M + PBM - 1) / PBM;
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+  const int m0 = (tile / tiles_n) * PBM, n0 = (tile % tiles_n) * PBN;
+  const int z = blockIdx.y;
+  const bf16_t* A = a.A + (int64_t)z * a.strideA;
+  const bf16_t* W = a.W + (int64_t)z * a.strideW;
+  const int nt = a.K / BK;
+
+  // this lane's 4 A rows and 4 W rows of every K tile (one 1 KiB slab = 8 rows per instruction)
+  const int sub = lane >> 3, cpos = lane & 7;
+  const bf16_t* a_src[4]; const bf16_t* w_src[4]; int a_dst[4], w_dst[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ra = 128 * g + 32 * wi + 8 * p + sub;                       // row inside the A tile
+    const int rw = 64 * wi + 32 * g + 8 * p + sub;                        // row inside the W tile
+    int gra = m0 + ra; gra = gra < a.M ? gra : a.M - 1;
+    int grw = n0 + rw; grw = grw < a.N ? grw : a.N - 1;
+    a_src[p] = A + (int64_t)gra * a.lda + ((cpos ^ ((ra >> 1) & 7)) << 3);
+    w_src[p] = W + (int64_t)grw * a.ldw + ((cpos ^ ((rw >> 1) & 7)) << 3);
+    a_dst[p] = (128 * g + 32 * wi + 8 * p) * 128;                         // wave-uniform slab base
+    w_dst[p] = PBM * BK * 2 + (64 * wi + 32 * g + 8 * p) * 128;
+  }
+  auto load_a = [&](int t, int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[p] + t * BK), (lds_ptr_t)(lds + buf * BUF_BYTES + a_dst[p]), 16, 0, 0);
+  };
+  auto load_w = [&](int t, int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[p] + t * BK), (lds_ptr_t)(lds + buf * BUF_BYTES + w_dst[p]), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[4][2], fw[2][2];                                              // [frag][kk]
+
+  auto read_a = [&](const char* buf, int half) {                           // 64 rows of this group's A half
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag(buf, 128 * g + 64 * half + 16 * i + (lane & 15), kk * 4 + (lane >> 4));
+  };
+  auto read_w = [&](const char* buf, int half) {                           // 32 rows of this wave's W slice
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fw[j][kk] = read_frag(buf + PBM * BK * 2, 64 * wi + 32 * half + 16 * j + (lane & 15), kk * 4 + (lane >> 4));
+  };
+#define SG_PP_MFMA(MH, NH)                                                                               \
+  do {                                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+          acc[4 * (MH) + i][2 * (NH) + j] =                                                              \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][kk], fa[i][kk], acc[4 * (MH) + i][2 * (NH) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+#define SG_PP_SYNC()                                 \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_barrier();                    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+
+  // De-synchronise the chip: every CU runs equal-length tiles, so without this all 256 epilogues (a 33-67 MB store burst)
+  // hit HBM at the same instant while every matrix pipe idles.  The first wave of workgroups starts in 4 time-shifted cohorts;
+  // later workgroups inherit the shift because they start when a CU frees up.
+  if (stagger > 0 && blockIdx.x < 256) {
+    const int cohort = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < cohort * stagger; ++i) __builtin_amdgcn_s_sleep(8);     // 512 cycles per iteration
+  }
+  // prologue: tile 0 completely, then the one-barrier stagger of group 1
+  load_a(0, 0); load_w(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SG_PP_SYNC();
+  if (g == 1) SG_PP_SYNC();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* buf = lds + (t & 1) * BUF_BYTES;
+    const bool more = t + 1 < nt;
+    // phase 0: quadrant (rows 0-63, cols 0-31)
+    read_w(buf, 0); read_a(buf, 0);
+    if (more) load_a(t + 1, (t + 1) & 1);
+    SG_PP_SYNC();
+    SG_PP_MFMA(0, 0);
+    SG_PP_SYNC();
+    // phase 1: (rows 0-63, cols 32-63)
+    read_w(buf, 1);
+    if (more) load_w(t + 1, (t + 1) & 1);
+    SG_PP_SYNC();
+    SG_PP_MFMA(0, 1);
+    SG_PP_SYNC();
+    // phase 2: (rows 64-127, cols 32-63)
+    read_a(buf, 1);
+    SG_PP_SYNC();
+    SG_PP_MFMA(1, 1);
+    SG_PP_SYNC();
+    // phase 3: (rows 64-127, cols 0-31)
+    read_w(buf, 0);
+    SG_PP_SYNC();
+    SG_PP_MFMA(1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile t+1 has landed
+    SG_PP_SYNC();
+  }
+  if (g == 0) SG_PP_SYNC();                               // balance the stagger barrier
+#undef SG_PP_MFMA
+#undef SG_PP_SYNC
+
+  if (vec) {
+    __syncthreads();
+    epilogue_store<8, 4>(acc, a, act, c_bf16, z, m0 + 128 * g, n0 + 64 * wi, reinterpret_cast<float*>(lds) + wave * 16 * 68, lane);
+    return;
+  }
+  const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + 128 * g + i * 16 + (lane & 15);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 64 * wi + j * 16 + (lane >> 4) * 4;
+      if (n >= a.N) continue;
+      float v[4] = {acc[i][j][0] * a.alpha, acc[i][j][1] * a.alpha, acc[i][j][2] * a.alpha, acc[i][j][3] * a.alpha};
+      if (vec) {
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (act == ACT_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        } else if (act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+        }
+        if (res) {
+          const float4 r = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+        if (c_bf16) {
+          bf16_t* C = reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
+          uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(C) = o;
+        } else {
+          float* C = reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
+          *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= a.N) break;
+          float x = v[e];
+          if (a.bias) x += a.bias[n + e];
+          if (act == ACT_QUICK_GELU) x = quick_gelu(x);
+          else if (act == ACT_GELU) x = erf_gelu(x);
+          if (res) x += res[(int64_t)m * a.ldr + n + e];
+          if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = f2bf(x);
+          else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
+        }
+      }
+    }
+  }
+}
+
+static int g_stagger = 0;
+void set_gemm_stagger(int v) { g_stagger = v; }
+static int launch_pingpong(const GemmBf16Args& a, int vec, hipStream_t s) {
+  const size_t lds = 2 * (256 + 256) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pingpong), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
+  hipLaunchKernelGGL(gemm_bf16_pingpong, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, vec,
+                     tiles > 256 ? g_stagger * (a.K / BK) / 8 : 0);
+  return SG_OK;
+}
+
+static int g_gemm_config = -1;                             // -1 = pick per shape
+void set_gemm_config(int c) { g_gemm_config = c; }
+
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0>
+static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
+  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE>;
+  const size_t lds = (size_t)STAGES * (BM_ + BN_) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
+  SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.batch), dim3(WM * WN * 64), lds, s, a, a.act, a.c_is_bf16, vec);
+  return SG_OK;
+}
+
 template <int ACT, bool C_BF16>
 static void launch(const GemmBf16Args& a, bool vec, dim3 grid, hipStream_t s) {
   if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<ACT, C_BF16, true>), grid, dim3(256), 0, s, a);
@@ -156,10 +600,39 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
              "gemm_bf16: operand strides must be multiples of 8 elements (16-byte chunks)");
   SG_REQUIRE((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0, "gemm_bf16: operands must be 16-byte aligned");
   const int csz = a.c_is_bf16 ? 2 : 4;
-  bool vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && (a.strideC % 4 == 0) && ((((uintptr_t)a.C) & 15) == 0);
+  bool vec = (a.N % 8 == 0) && (a.ldc % 8 == 0) && (a.strideC % 8 == 0) && ((((uintptr_t)a.C) & 15) == 0);
   if (a.bias) vec = vec && ((((uintptr_t)a.bias) & 15) == 0);
   if (a.residual) vec = vec && (a.ldr % 4 == 0) && ((((uintptr_t)a.residual) & 15) == 0);
   (void)csz;
+  SG_REQUIRE(a.act >= 0 && a.act <= 2, "gemm_bf16: bad act %d", a.act);
+  int cfg = g_gemm_config;
+  if (cfg < 0) cfg = (a.M >= 1024 && a.N >= 512) ? 7 : 4;  // small problems keep the 128x128 tile (more workgroups)
+  if (cfg > 0) {
+    prof_begin(PROF_GEMM_BF16, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
+    int rc;
+    switch (cfg) {
+      case 1: rc = launch_ring<128, 128, 2, 2, 3>(a, vec, s); break;
+      case 2: rc = launch_ring<256, 128, 4, 2, 3>(a, vec, s); break;
+      case 3: rc = launch_ring<256, 256, 2, 4, 2>(a, vec, s); break;
+      case 4: rc = launch_ring<128, 128, 2, 2, 2>(a, vec, s); break;
+      case 5: rc = launch_ring<256, 128, 4, 2, 2>(a, vec, s); break;
+      case 6: rc = launch_ring<128, 256, 2, 4, 3>(a, vec, s); break;
+      case 7: rc = launch_pingpong(a, vec, s); break;
+      case 11: rc = launch_ring<256, 256, 2, 4, 2, 1>(a, vec, s); break;   // ablations (wrong results by design)
+      case 12: rc = launch_ring<256, 256, 2, 4, 2, 2>(a, vec, s); break;
+      case 13: rc = launch_ring<128, 128, 2, 2, 2, 1>(a, vec, s); break;
+      case 15: rc = launch_ring<256, 256, 2, 4, 2, 3>(a, vec, s); break;
+      case 16: rc = launch_ring<256, 256, 2, 4, 2, 4>(a, vec, s); break;
+      case 17: rc = launch_ring<128, 128, 2, 2, 2, 3>(a, vec, s); break;
+      case 18: rc = launch_ring<128, 128, 2, 2, 2, 4>(a, vec, s); break;
+      case 14: rc = launch_ring<128, 128, 2, 2, 2, 2>(a, vec, s); break;
+      default: return fail(SG_ERR_INVALID, "gemm_bf16: unknown tile config %d", cfg);
+    }
+    prof_end(PROF_GEMM_BF16, s);
+    if (rc != SG_OK) return rc;
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+  }
   const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   dim3 grid((unsigned)tiles, (unsigned)a.batch);

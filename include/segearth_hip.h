@@ -110,6 +110,7 @@ int sg_version(void);
  * category: 0 = bf16 MFMA GEMM, 1 = fused attention, 2 = f32 MFMA GEMM.  Read after synchronising. */
 int sg_profile_enable(int capacity);
 int sg_profile_disable(void);
+int sg_set_gemm_config(int cfg);   /* tuning hook: bf16 GEMM tile variant, -1 = automatic */
 int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped);
 
 /* ---- context and weights ------------------------------------------------------------------
@@ -174,6 +175,9 @@ int sg_similarity_map(const float* patches, int64_t batch_stride, int ld, int B,
  * `precision`.  act: 0 none, 1 QuickGELU, 2 erf GELU. */
 int sg_op_linear(const float* A, const float* W, const float* bias, const float* residual, float* C,
                  int M, int N, int K, int act, int precision, void* scratch, size_t scratch_bytes, sg_stream s);
+/* bf16 GEMM on caller-packed operands: A [M,K], W [N,K] bf16 (K % 64 == 0), C bf16 or f32 */
+int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
+                     int act, int c_is_bf16, sg_stream s);
 int sg_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, sg_stream s);
 /* multi-term attention over packed qkv [B,N,3D] (rows q|k|v, nn.MultiheadAttention order);
  * variant = enum sg_model_type (SG_VANILLA = ordinary softmax(q k^T) v). bias: [B,n,n] or NULL.
