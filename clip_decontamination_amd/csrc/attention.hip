@@ -60,7 +60,7 @@ __device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u
 // GENERIC = additive bias and / or the 'Experimental' re-softmax (last block only); the 23 ordinary blocks run the lean path.
 // MULTI = several separately soft-maxed streams are summed (SCLIP / SegEarth / GEM); otherwise no second accumulator.
 template <int DH, int TS, bool GENERIC, bool MULTI>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = TS * KT * C::K_LD + KT * C::V_LD;                 // elements per LDS buffer: [TS K tiles][V tile]
@@ -126,78 +126,87 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       const bf16_t* sK = sbuf + cur * BUF;
       const bf16_t* sV = sK + TS * KT * C::K_LD;
 
+      // ---- scores of the whole 64-key tile: S^T[key][query], 2 sub-blocks x KS k-steps -----------------------------
+      f32x16 sacc[2];
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        const int kb = k0 + sub * 32;
-        if (kb >= a.N) break;                                // block-uniform
-        f32x16 sacc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
 #pragma unroll
         for (int t = 0; t < TS; ++t)
 #pragma unroll
           for (int ks = 0; ks < C::KS; ++ks) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], sacc, 0, 0, 0);   // S^T[key][query]
+            sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], sacc[sub], 0, 0, 0);
           }
-        // log2-domain scores for query q_glob (lane) and keys kb + (r&3) + 8 (r>>2) + 4 h
-        float sc[16];
-        if (GENERIC) {
+      }
+      // log2-domain scores for query q_glob (lane); key of (sub, r) = k0 + 32 sub + (r&3) + 8 (r>>2) + 4 h
+      float sc[32];
+      float mloc;
+      if (GENERIC) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float bv = 0.f;
-            if (a.bias && key >= 1 && key < a.N && q_ld >= 1) bv = a.bias_w * a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)];
-            float v = sacc[r] * c2;
-            if (a.resoftmax) v = (exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
-            sc[r] = key < a.N ? v : -INFINITY;
-          }
-        } else if (kb + 32 > a.N) {                          // tail sub-block: mask keys past the end
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = (kb + (r & 3) + 8 * (r >> 2) + 4 * h) < a.N ? sacc[r] * c2 : -INFINITY;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = sacc[r] * c2;
+        for (int i = 0; i < 32; ++i) {
+          const int key = k0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
+          float bv = 0.f;
+          if (a.bias && key >= 1 && key < a.N && q_ld >= 1) bv = a.bias_w * a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)];
+          float v = sacc[i >> 4][i & 15] * c2;
+          if (a.resoftmax) v = (__builtin_amdgcn_exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
+          sc[i] = key < a.N ? v : -INFINITY;
         }
-        float mloc = sc[0];
+        mloc = sc[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sc[r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
-        float lsum = 0.f;
+        for (int i = 1; i < 32; ++i) mloc = fmaxf(mloc, sc[i]);
+      } else {
+        if (k0 + KT > a.N) {                               // tail tile: mask keys past the end (block-uniform branch)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[r] = exp2f(sc[r] - m_new); lsum += sc[r]; }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        const bool grew = m_new > m_run;
-        m_run = m_new;
-        if (do_pv) {
-          if (__any(grew)) {                                 // wave-uniform: skip the rescale when no row maximum moved
+          for (int i = 0; i < 32; ++i)
+            if (k0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h >= a.N) sacc[i >> 4][i & 15] = -INFINITY;
+        }
+        mloc = sacc[0][0];
 #pragma unroll
-            for (int t = 0; t < C::DVT; ++t)
+        for (int i = 1; i < 32; ++i) mloc = fmaxf(mloc, sacc[i >> 4][i & 15]);
+        mloc *= c2;                                        // c2 > 0: max commutes with the scaling
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float lsum = 0.f;
 #pragma unroll
-              for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
-          }
-          bf16x8 pf[2];
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[s2][j] = (__bf16)sc[8 * s2 + j];
-          // V^T fragments by transposed LDS read: lane 4q+p of a 16-lane group addresses row q, cols 4p..4p+3
+      for (int i = 0; i < 32; ++i) {
+        const float x = GENERIC ? sc[i] - m_new : fmaf(sacc[i >> 4][i & 15], c2, -m_new);
+        sc[i] = __builtin_amdgcn_exp2f(x);
+        lsum += sc[i];
+      }
+      lsum += __shfl_xor(lsum, 32, 64);
+      l_run = l_run * alpha + lsum;
+      const bool grew = m_new > m_run;
+      m_run = m_new;
+      if (do_pv) {
+        if (__any(grew)) {                                 // wave-uniform: skip the rescale when no row maximum moved
 #pragma unroll
           for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-              const int key0 = sub * 32 + s2 * 16 + 4 * h;
-              const bf16_t* p0 = sV + (key0 + qq) * C::V_LD + t * 32 + 16 * (g & 1) + 4 * pp;
-              const short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0));
-              const short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0 + 8 * C::V_LD));
-              typedef __attribute__((ext_vector_type(8))) short short8_;
-              short8_ vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-              o_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[s2], o_acc[t], 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
         }
+        // P (bf16) is already the B operand: element j of k-step s2 of sub-block sub = sc[16 sub + 8 s2 + j]
+        bf16x8 pf[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
+        // V^T fragments by transposed LDS read: lane 4q+p of a 16-lane group addresses row q, cols 4p..4p+3
+#pragma unroll
+        for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const int key0 = f * 16 + 4 * h;
+            const bf16_t* p0 = sV + (key0 + qq) * C::V_LD + t * 32 + 16 * (g & 1) + 4 * pp;
+            const short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0));
+            const short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0 + 8 * C::V_LD));
+            typedef __attribute__((ext_vector_type(8))) short short8_;
+            short8_ vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[f], o_acc[t], 0, 0, 0);
+          }
       }
       if (has_next) {                                        // the other buffer was last read one iteration ago
         bf16_t* nK = sbuf + (cur ^ 1) * BUF;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
   }
 
-  if (a.lse_out && h == 0 && q_glob < a.N) a.lse_out[((int64_t)b * a.H + hd) * a.N + q_glob] = (m_run + log2f(l_run)) * LN2;
+  if (a.lse_out && h == 0 && q_glob < a.N) a.lse_out[((int64_t)b * a.H + hd) * a.N + q_glob] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
   if (do_pv && q_glob < a.N) {
     bf16_t* op = a.ctx + (int64_t)b * a.ctx_sb + (int64_t)q_glob * a.ctx_st + (int64_t)hd * DH;
 #pragma unroll
