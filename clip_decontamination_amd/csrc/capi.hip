@@ -306,7 +306,6 @@ extern "C" int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias,
 }
 // Tuning hook for the bf16 GEMM tile configuration (-1 = automatic).
 extern "C" int sg_set_gemm_config(int cfg) {
-  if (cfg >= 100) { set_gemm_stagger(cfg - 100); return SG_OK; }       // 100 + s: start-time stagger (units of ~8k cycles x K tiles / 64)
   set_gemm_config(cfg);
   return SG_OK;
 }

@@ -103,7 +103,6 @@ struct GemmBf16Args {
   float alpha;                                        // applied to the accumulator before bias
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
-void set_gemm_stagger(int v);
 void set_gemm_config(int c);   // tuning hook: -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
 
 // f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];

@@ -219,14 +219,19 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
 // refilled immediately -- so STAGES-1 tiles of HBM/L2 latency are hidden behind the MFMA phase instead of one.
 //   iteration t:  vmcnt((STAGES-2) * G) ; s_barrier ; stage(t + STAGES - 1) ; ds_read + MFMA on slot t % STAGES
 // Slot (t-1) % STAGES is rewritten only after every wave has passed the barrier that follows its last read of it.
+__device__ __forceinline__ int swz32(int r) { return (0 - (r >> 2)) & 3; }
+__device__ __forceinline__ bf16x8 read_frag32(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((chunk ^ swz32(row)) << 4));
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MI = TM / 16, NI = TN / 16;
-  constexpr int SLABS = (BM_ + BN_) / 8;                 // 1 KiB slabs (8 rows x 128 B) per K tile
+  constexpr int RPS = BKT == 64 ? 8 : 16;                // rows per 1 KiB slab (row = BKT * 2 bytes)
+  constexpr int SLABS = (BM_ + BN_) / RPS;               // 1 KiB slabs per K tile
   constexpr int G = SLABS / NW;                          // global_load_lds per thread per K tile
-  constexpr int STAGE_BYTES = (BM_ + BN_) * BK * 2;
+  constexpr int STAGE_BYTES = (BM_ + BN_) * BKT * 2;
   static_assert(SLABS % NW == 0, "slabs must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,12 +253,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring(GemmBf16Args a, i
 #pragma unroll
     for (int p = 0; p < G; ++p) {
       const int slab = p * NW + wave;                      // wave-uniform
-      const int r = slab * 8 + (lane >> 3);                // row inside the stacked [A rows | W rows] image
-      const int c = lane & 7;
-      const int gch = c ^ ((r >> 1) & 7);
+      const int r = slab * RPS + (BKT == 64 ? (lane >> 3) : (lane >> 2));   // row inside the stacked [A rows | W rows] image
+      const int c = BKT == 64 ? (lane & 7) : (lane & 3);
+      const bool is_a = slab * RPS < BM_;
+      const int rl = is_a ? r : r - BM_;                   // the swizzle is a function of the row inside its own tile
+      const int gch = BKT == 64 ? (c ^ ((rl >> 1) & 7)) : (c ^ swz32(rl));
       const bf16_t* src;
-      if (slab * 8 < BM_) { int gr = m0 + r; gr = gr < a.M ? gr : a.M - 1; src = A + (int64_t)gr * a.lda + t * BK + gch * 8; }
-      else { int gr = n0 + r - BM_; gr = gr < a.N ? gr : a.N - 1; src = W + (int64_t)gr * a.ldw + t * BK + gch * 8; }
+      if (is_a) { int gr = m0 + r; gr = gr < a.M ? gr : a.M - 1; src = A + (int64_t)gr * a.lda + t * BKT + gch * 8; }
+      else { int gr = n0 + rl; gr = gr < a.N ? gr : a.N - 1; src = W + (int64_t)gr * a.ldw + t * BKT + gch * 8; }
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + slab * 1024), 16, 0, 0);
     }
   };
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring(GemmBf16Args a, i
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = ABLATE == 4 ? 1 : a.K / BK;
+  const int nt = ABLATE == 4 ? 1 : a.K / BKT;
 #pragma unroll
   for (int sidx = 0; sidx < STAGES - 1; ++sidx)
     if (sidx < nt) stage(sidx, sidx);
@@ -278,15 +285,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring(GemmBf16Args a, i
     asm volatile("" ::: "memory");
     if (ABLATE != 1 && t + STAGES - 1 < nt) stage(t + STAGES - 1, (t + STAGES - 1) % STAGES);
     const char* bufA = lds + (t % STAGES) * STAGE_BYTES;
-    const char* bufW = bufA + BM_ * BK * 2;
+    const char* bufW = bufA + BM_ * BKT * 2;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BKT / 32; ++kk) {
       const int chunk = kk * 4 + (lane >> 4);
       bf16x8 fa[MI], fw[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = read_frag(bufA, wave_m * TM + i * 16 + (lane & 15), chunk);
+      for (int i = 0; i < MI; ++i)
+        fa[i] = BKT == 64 ? read_frag(bufA, wave_m * TM + i * 16 + (lane & 15), chunk) : read_frag32(bufA, wave_m * TM + i * 16 + (lane & 15), chunk);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fw[j] = read_frag(bufW, wave_n * TN + j * 16 + (lane & 15), chunk);
+      for (int j = 0; j < NI; ++j)
+        fw[j] = BKT == 64 ? read_frag(bufW, wave_n * TN + j * 16 + (lane & 15), chunk) : read_frag32(bufW, wave_n * TN + j * 16 + (lane & 15), chunk);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring(GemmBf16Args a, i
 //   * RAW: every wave drains its own loads (vmcnt(0)) at the end of MFMA(t,3) (slot 8t+7 / 8t+8) before the barrier; the first
 //     readers of another group's rows come >= 1 slot after that barrier (group 0 reads group-1-loaded W rows in READ(t+1,1),
 //     slot 8t+10; group 1 reads group-0-loaded W rows in READ(t+1,0), slot 8t+9).
-__global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int act, int c_bf16, int vec, int stagger) {
+__global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int PBM = 256, PBN = 256;
   constexpr int BUF_BYTES = (PBM + PBN) * BK * 2;          // 64 KiB
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -453,13 +462,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
     __builtin_amdgcn_sched_barrier(0);               \
   } while (0)
 
-  // De-synchronise the chip: every CU runs equal-length tiles, so without this all 256 epilogues (a 33-67 MB store burst)
-  // hit HBM at the same instant while every matrix pipe idles.  The first wave of workgroups starts in 4 time-shifted cohorts;
-  // later workgroups inherit the shift because they start when a CU frees up.
-  if (stagger > 0 && blockIdx.x < 256) {
-    const int cohort = (blockIdx.x >> 3) & 3;
-    for (int i = 0; i < cohort * stagger; ++i) __builtin_amdgcn_s_sleep(8);     // 512 cycles per iteration
-  }
   // prologue: tile 0 completely, then the one-barrier stagger of group 1
   load_a(0, 0); load_w(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -553,8 +555,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
   }
 }
 
-static int g_stagger = 0;
-void set_gemm_stagger(int v) { g_stagger = v; }
 static int launch_pingpong(const GemmBf16Args& a, int vec, hipStream_t s) {
   const size_t lds = 2 * (256 + 256) * BK * 2;
   static bool attr_set = false;
@@ -564,18 +564,167 @@ static int launch_pingpong(const GemmBf16Args& a, int vec, hipStream_t s) {
   }
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
-  hipLaunchKernelGGL(gemm_bf16_pingpong, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, vec,
-                     tiles > 256 ? g_stagger * (a.K / BK) / 8 : 0);
+  hipLaunchKernelGGL(gemm_bf16_pingpong, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, vec);
+  return SG_OK;
+}
+
+// ---- ping-pong, K tile 32, FOUR-deep LDS ring ---------------------------------------------------------------------------------
+// Same two-group alternation as gemm_bf16_pingpong, but a K tile is 32 deep (2 phases x 16 MFMAs) and the 128 KiB of LDS hold a
+// ring of 4 tiles, so the loads of tile t+3 are issued while tile t computes: three tiles (~3000 cycles) of HBM / fabric latency
+// are covered instead of one, with only 2 global_load_lds per wave per phase (their issue cost stays inside a 256-cycle segment).
+// LDS image per tile: [A 256 rows x 64 B | W 256 rows x 64 B]; 16-byte chunk c of row r sits at position c ^ swz(r),
+// swz(r) = (-(r >> 2)) & 3, which makes every ds_read_b128 lane group of a 16-row fragment read hit 16 distinct bank slots.
+// Slot = barrier interval; group 0: READ(t,0) = 4t, MFMA(t,0) = 4t+1, READ(t,1) = 4t+2, MFMA(t,1) = 4t+3; group 1 one later.
+//   loads : wave (g,i) issues for tile t+3   A rows [128g+32i,+32) in READ(t,0),   W rows [64i+32g,+32) in READ(t,1)
+//   WAR   : ring slot (t+3)&3 was last read for tile t-1: A-half g by group g in READ(t-1,1) (slot 4t-2+g, retired when the
+//           next segment opens), W rows in READ(t-1,0) (slots 4t-4 / 4t-3); the writes are issued at slots >= 4t+g / 4t+2+g.
+//   RAW   : each wave retires its own pieces of tile t+1 with a COUNTED vmcnt (tiles t+2, t+3 stay in flight) just before
+//           the barrier that closes slot 4t+3 (group 0: after MFMA(t,1); group 1: after READ(t,1)); tile t+1 is first read
+//           in slot 4t+4.
+
+template <int ABLATE>
+__global__ __launch_bounds__(512) void gemm_bf16_pp32(GemmBf16Args a, int act, int c_bf16, int vec) {
+  constexpr int PBM = 256, PBN = 256, KT32 = 32;
+  constexpr int TILE_B = (PBM + PBN) * KT32 * 2;             // 32 KiB per ring slot
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wi = wave & 3;
+  const int tiles_n = (a.N + PBN - 1) / PBN, tiles_m = (a.M + PBM - 1) / PBM;
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+  const int m0 = (tile / tiles_n) * PBM, n0 = (tile % tiles_n) * PBN;
+  const int z = blockIdx.y;
+  const bf16_t* A = a.A + (int64_t)z * a.strideA;
+  const bf16_t* W = a.W + (int64_t)z * a.strideW;
+  const int nt = ABLATE == 4 ? 4 : a.K / KT32;
+
+  // this lane's source rows: 2 A slabs and 2 W slabs (16 rows x 64 B each) per K tile
+  const int srow = lane >> 2, cpos = lane & 3;
+  const bf16_t* a_src[2]; const bf16_t* w_src[2]; int a_dst[2], w_dst[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int ra = 128 * g + 32 * wi + 16 * p + srow;
+    const int rw = 64 * wi + 32 * g + 16 * p + srow;
+    int gra = m0 + ra; gra = gra < a.M ? gra : a.M - 1;
+    int grw = n0 + rw; grw = grw < a.N ? grw : a.N - 1;
+    a_src[p] = A + (int64_t)gra * a.lda + ((cpos ^ swz32(ra)) << 3);
+    w_src[p] = W + (int64_t)grw * a.ldw + ((cpos ^ swz32(rw)) << 3);
+    a_dst[p] = (128 * g + 32 * wi + 16 * p) * 64;
+    w_dst[p] = PBM * KT32 * 2 + (64 * wi + 32 * g + 16 * p) * 64;
+  }
+  auto load_a = [&](int t) {
+    char* base = lds + (t & 3) * TILE_B;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[p] + t * KT32), (lds_ptr_t)(base + a_dst[p]), 16, 0, 0);
+  };
+  auto load_w = [&](int t) {
+    char* base = lds + (t & 3) * TILE_B;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[p] + t * KT32), (lds_ptr_t)(base + w_dst[p]), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[4], fw[4];
+
+#define SG_P32_SYNC()                                \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_barrier();                    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#define SG_P32_MFMA(MH)                                                                                  \
+  do {                                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+        if (ABLATE != 2) acc[4 * (MH) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[4 * (MH) + i][j], 0, 0, 0); \
+        else asm volatile("" ::"v"(fw[j]), "v"(fa[i]));                                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+#define SG_P32_WAIT(T)                                                                                   \
+  do {                                                                                                   \
+    const int beyond = nt - 2 - (T);                                                                     \
+    if (beyond >= 2) wait_vmcnt<8>(); else if (beyond == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();       \
+  } while (0)
+
+  // prologue: tiles 0..2 in flight, tile 0 retired; then the one-barrier stagger of group 1
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < nt) { load_a(t); load_w(t); }
+  SG_P32_WAIT(-1);
+  SG_P32_SYNC();
+  if (g == 1) SG_P32_SYNC();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* tA = lds + (t & 3) * TILE_B;
+    const char* tW = tA + PBM * KT32 * 2;
+    const bool more = (ABLATE != 1) && (t + 3 < nt);
+    // phase 0: rows 0-63 of the group's half x the wave's 64 columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw[j] = read_frag32(tW, 64 * wi + 16 * j + (lane & 15), lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = read_frag32(tA, 128 * g + 16 * i + (lane & 15), lane >> 4);
+    if (more) load_a(t + 3);
+    SG_P32_SYNC();
+    SG_P32_MFMA(0);
+    SG_P32_SYNC();
+    // phase 1: rows 64-127
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = read_frag32(tA, 128 * g + 64 + 16 * i + (lane & 15), lane >> 4);
+    if (more) load_w(t + 3);
+    if (g == 1) SG_P32_WAIT(t);
+    SG_P32_SYNC();
+    SG_P32_MFMA(1);
+    if (g == 0) SG_P32_WAIT(t);
+    SG_P32_SYNC();
+  }
+  if (g == 0) SG_P32_SYNC();
+#undef SG_P32_SYNC
+#undef SG_P32_MFMA
+#undef SG_P32_WAIT
+
+  if (ABLATE == 3) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 1234.5678f) reinterpret_cast<float*>(a.C)[0] = sum;
+    return;
+  }
+  __syncthreads();
+  epilogue_store<8, 4>(acc, a, act, c_bf16, z, m0 + 128 * g, n0 + 64 * wi, reinterpret_cast<float*>(lds) + wave * 16 * 68, lane);
+}
+
+template <int ABLATE>
+static int launch_pp32(const GemmBf16Args& a, hipStream_t s) {
+  const size_t lds = 4 * (256 + 256) * 32 * 2;
+  auto kern = gemm_bf16_pp32<ABLATE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, 1);
   return SG_OK;
 }
 
 static int g_gemm_config = -1;                             // -1 = pick per shape
 void set_gemm_config(int c) { g_gemm_config = c; }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64>
 static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
-  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE>;
-  const size_t lds = (size_t)STAGES * (BM_ + BN_) * BK * 2;
+  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT>;
+  const size_t lds = (size_t)STAGES * (BM_ + BN_) * BKT * 2;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -618,6 +767,13 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
       case 5: rc = launch_ring<256, 128, 4, 2, 2>(a, vec, s); break;
       case 6: rc = launch_ring<128, 256, 2, 4, 3>(a, vec, s); break;
       case 7: rc = launch_pingpong(a, vec, s); break;
+      case 9: rc = launch_ring<128, 256, 1, 4, 3, 0, 32>(a, vec, s); break;    // 72 KiB LDS: two workgroups per CU
+      case 10: rc = launch_ring<256, 128, 4, 1, 3, 0, 32>(a, vec, s); break;
+      case 8: rc = vec ? launch_pp32<0>(a, s) : launch_pingpong(a, vec, s); break;
+      case 21: rc = launch_pp32<1>(a, s); break;          // ablations of the pp32 kernel (wrong results by design)
+      case 22: rc = launch_pp32<2>(a, s); break;
+      case 23: rc = launch_pp32<3>(a, s); break;
+      case 24: rc = launch_pp32<4>(a, s); break;
       case 11: rc = launch_ring<256, 256, 2, 4, 2, 1>(a, vec, s); break;   // ablations (wrong results by design)
       case 12: rc = launch_ring<256, 256, 2, 4, 2, 2>(a, vec, s); break;
       case 13: rc = launch_ring<128, 128, 2, 2, 2, 1>(a, vec, s); break;

@@ -10,8 +10,6 @@ dev = "cuda:0"
 M = 32 * 1370
 SHAPES = [("qkv", M, 3072, 1024, 0, 1), ("out", M, 1024, 1024, 0, 0), ("fc", M, 4096, 1024, 1, 1), ("proj", M, 1024, 4096, 0, 0)]
 CONFIGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6".split(","))]
-if len(sys.argv) > 2:
-    lib.sg_set_gemm_config(100 + int(sys.argv[2]))
 ROUNDS, ITERS = 5, 10
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
