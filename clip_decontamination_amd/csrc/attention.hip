@@ -59,8 +59,10 @@ __device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u
 
 // GENERIC = additive bias and / or the 'Experimental' re-softmax (last block only); the 23 ordinary blocks run the lean path.
 // MULTI = several separately soft-maxed streams are summed (SCLIP / SegEarth / GEM); otherwise no second accumulator.
+// Lean variants are capped at 256 registers (VGPR-form MFMA, 2+ waves per SIMD); the register-hungry ones (bias + multi-stream,
+// head_dim > 64) may take the whole file rather than spill.
 template <int DH, int TS, bool GENERIC, bool MULTI>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void attn_kernel(AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = TS * KT * C::K_LD + KT * C::V_LD;                 // elements per LDS buffer: [TS K tiles][V tile]
@@ -116,6 +118,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     __syncthreads();
     int cur = 0;
 
+    // GENERIC: the additive bias (similarity map) of the NEXT key tile is fetched one tile ahead -- 32 coalesced dword loads per
+    // lane (the map is symmetric, so it is read as bias[key][query] with the queries on the lanes)
+    float bnext[GENERIC ? 32 : 1];
+    auto fetch_bias = [&](int kbase) {
+      if (GENERIC && a.bias) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
+          bnext[i] = (key >= 1 && key < a.N && q_ld >= 1) ? a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)] : 0.f;
+        }
+      }
+    };
+    fetch_bias(0);
     for (int k0 = 0; k0 < a.N; k0 += KT) {
       const bool has_next = k0 + KT < a.N;
       if (has_next) {                                        // next tile's loads fly while this tile computes
@@ -147,12 +162,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = k0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-          float bv = 0.f;
-          if (a.bias && key >= 1 && key < a.N && q_ld >= 1) bv = a.bias_w * a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)];
+          const float bv = a.bias ? bnext[i] * a.bias_w : 0.f;
           float v = sacc[i >> 4][i & 15] * c2;
           if (a.resoftmax) v = (__builtin_amdgcn_exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
           sc[i] = key < a.N ? v : -INFINITY;
         }
+        if (has_next) fetch_bias(k0 + KT);                 // lands under this tile's softmax / PV and the next tile's QK^T
         mloc = sc[0];
 #pragma unroll
         for (int i = 1; i < 32; ++i) mloc = fmaxf(mloc, sc[i]);

@@ -79,7 +79,8 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // activations of the MLP (reference open_clip/transformer.py:35-38 / nn.GELU)
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// throughput-mode QuickGELU: x * rcp(1 + 2^(-1.702 log2e x)) -- v_exp_f32 + v_rcp_f32 (1 ulp each), inputs end up in bf16 anyway
+__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x)); }
 __device__ __forceinline__ float quick_gelu_exact(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }
 __device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -718,6 +718,229 @@ static int launch_pp32(const GemmBf16Args& a, hipStream_t s) {
   return SG_OK;
 }
 
+// ---- persistent ping-pong: the production kernel for the large ViT linears ---------------------------------------------------------
+// gemm_bf16_pp32's ring (K tile 32, four slots) with three changes measured to matter:
+//   * ONE phase of 32 MFMAs per K tile (12 ds_read_b128 + 4 global_load_lds per wave per READ segment): the barrier + LDS-latency
+//     overhead of a READ segment is amortised over a 512-cycle MFMA segment instead of 256;
+//   * PERSISTENT workgroups (grid = #CUs): the K-tile stream runs straight across output tiles, so the loads of the next
+//     tile's first K tiles are already in flight while the current tile's epilogue drains -- no exposed prologue per tile;
+//   * asymmetric issue so every piece gets >= 3 slots of flight:   group 0 READ(s): W(s+2), A(s+3)    group 1 READ(s): A(s+3), W(s+3)
+// Slots (barrier intervals): group 0 READ(s) = 2s, MFMA(s) = 2s+1; group 1 READ(s) = 2s+1, MFMA(s) = 2s+2.
+//   WAR  ring slot (s+3)&3 = (s-1)&3: A-half g last read by group g in READ(s-1) (slot 2s-2+g), retired when the next segment opens
+//        (2s-1+g); written at slot 2s+g.  W rows of slot (s-1)&3 last read at slots 2s-2 / 2s-1, retired by the start of slot 2s;
+//        group 1 writes them at slot 2s+1.  Group 0's W(s+2) goes to slot (s-2)&3, idle since slot 2s-3.
+//   RAW  K tile s+1 is first read in slot 2s+2.  Group 0 retires its pieces of it after MFMA(s) (allowed outstanding:
+//        A(s+2), W(s+2), A(s+3) = 6), group 1 after READ(s) (tiles s+2, s+3 = 8); both before the barrier closing slot 2s+1.
+//   tile end: group 0 takes one extra barrier (both groups are then past every read of the tile's last K tile), every wave runs the
+//        coalescing epilogue through a private patch inside the just-consumed ring slot, one barrier, group 1 re-staggers.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
+                                                int col0, float* patch, int lane) {
+  constexpr int TN = NI * 16, LDP = TN + 4;
+  const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
+  float4 bias4[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = col0 + j * 16 + (lane >> 4) * 4;
+    bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && n + 3 < a.N) bias4[j] = *reinterpret_cast<const float4*>(a.bias + n);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float4 v4[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float v[4] = {acc[i][j][0] * a.alpha + bias4[j].x, acc[i][j][1] * a.alpha + bias4[j].y, acc[i][j][2] * a.alpha + bias4[j].z,
+                    acc[i][j][3] * a.alpha + bias4[j].w};
+      if (act == ACT_QUICK_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+      } else if (act == ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+      }
+      v4[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {                       // two 8-row strips per 16-row MFMA tile
+      if (((lane >> 3) & 1) == hh) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) *reinterpret_cast<float4*>(patch + (lane & 7) * LDP + j * 16 + (lane >> 4) * 4) = v4[j];
+      }
+      const int rbase = row0 + i * 16 + hh * 8;
+      if (c_bf16) {                                        // 8 lanes x 16 B per row: one instruction stores the whole strip
+        constexpr int LPR = TN / 8;
+        const int r = lane / LPR, cq = (lane % LPR) * 8;
+        const int m = rbase + r, n = col0 + cq;
+        if (r < 8 && m < a.M && n < a.N) {
+          const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
+          uint4 o; o.x = pack_bf2(x0.x, x0.y); o.y = pack_bf2(x0.z, x0.w); o.z = pack_bf2(x1.x, x1.y); o.w = pack_bf2(x1.z, x1.w);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
+        }
+      } else {
+        constexpr int LPR = TN / 4;
+        constexpr int RPP = 64 / LPR;
+#pragma unroll
+        for (int r0 = 0; r0 < 8; r0 += RPP) {
+          const int r = r0 + lane / LPR, cq = (lane % LPR) * 4;
+          const int m = rbase + r, n = col0 + cq;
+          if (r < 8 && m < a.M && n < a.N) {
+            float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+            if (res) {
+              const float4 rr = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
+              x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
+            }
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = x;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act, int c_bf16) {
+  constexpr int PBM = 256, PBN = 256, KT32 = 32;
+  constexpr int TILE_B = (PBM + PBN) * KT32 * 2;             // 32 KiB per ring slot
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wi = wave & 3;
+  const int tiles_n = (a.N + PBN - 1) / PBN, tiles_m = (a.M + PBM - 1) / PBM;
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int z = blockIdx.y;
+  const bf16_t* A = a.A + (int64_t)z * a.strideA;
+  const bf16_t* W = a.W + (int64_t)z * a.strideW;
+  const int nt = a.K / KT32;
+  const int my_tiles = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nt;                          // length of this workgroup's K-tile stream
+
+  const int srow = lane >> 2, cpos = lane & 3;
+  struct Src { const bf16_t* a[2]; const bf16_t* w[2]; int m0, n0; };
+  auto make_src = [&](int j) {
+    Src sp;
+    const int v = (int)blockIdx.x + j * (int)gridDim.x;      // virtual id; XCD x = v & 7 walks a contiguous chunk of tile ids
+    const int xcd = v & 7, seq = v >> 3;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+    tile = tile < nwg ? tile : nwg - 1;
+    sp.m0 = (tile / tiles_n) * PBM; sp.n0 = (tile % tiles_n) * PBN;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int ra = 128 * g + 32 * wi + 16 * p + srow;
+      const int rw = 64 * wi + 32 * g + 16 * p + srow;
+      int gra = sp.m0 + ra; gra = gra < a.M ? gra : a.M - 1;
+      int grw = sp.n0 + rw; grw = grw < a.N ? grw : a.N - 1;
+      sp.a[p] = A + (int64_t)gra * a.lda + ((cpos ^ swz32(ra)) << 3);
+      sp.w[p] = W + (int64_t)grw * a.ldw + ((cpos ^ swz32(rw)) << 3);
+    }
+    return sp;
+  };
+  int a_dst[2], w_dst[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    a_dst[p] = (128 * g + 32 * wi + 16 * p) * 64;
+    w_dst[p] = PBM * KT32 * 2 + (64 * wi + 32 * g + 16 * p) * 64;
+  }
+  Src cur = make_src(0);
+  Src nxt = make_src(my_tiles > 1 ? 1 : 0);
+  int cur_end = nt;                                          // stream index where `nxt` begins
+  auto load_a = [&](int u) {
+    if (u >= total) return;
+    const Src& sp = u >= cur_end ? nxt : cur;
+    const int kt = u >= cur_end ? u - cur_end : u - (cur_end - nt);
+    char* base = lds + (u & 3) * TILE_B;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sp.a[p] + kt * KT32), (lds_ptr_t)(base + a_dst[p]), 16, 0, 0);
+  };
+  auto load_w = [&](int u) {
+    if (u >= total) return;
+    const Src& sp = u >= cur_end ? nxt : cur;
+    const int kt = u >= cur_end ? u - cur_end : u - (cur_end - nt);
+    char* base = lds + (u & 3) * TILE_B;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sp.w[p] + kt * KT32), (lds_ptr_t)(base + w_dst[p]), 16, 0, 0);
+  };
+  // retire this wave's pieces of K tile u, leaving younger pieces in flight
+  auto wait_tile = [&](int u) {
+    if (g == 0) { if (u + 2 < total) wait_vmcnt<6>(); else if (u + 1 < total) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+    else { if (u + 2 < total) wait_vmcnt<8>(); else if (u + 1 < total) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+  };
+#define SG_PS_SYNC()                                 \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_barrier();                    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+
+  // prologue (group 0 holds W(2) back: it is issued in READ(0) as W(s+2))
+  load_a(0); load_w(0); load_a(1); load_w(1); load_a(2);
+  if (g == 1) load_w(2);
+  wait_tile(0);
+  SG_PS_SYNC();
+  if (g == 1) SG_PS_SYNC();
+
+  f32x4 acc[8][4];
+  bf16x8 fa[8], fw[4];
+  int s = 0;
+  for (int j = 0; j < my_tiles; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nt; ++kt, ++s) {
+      const char* tA = lds + (s & 3) * TILE_B;
+      const char* tW = tA + PBM * KT32 * 2;
+      // READ(s)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) fw[jj] = read_frag32(tW, 64 * wi + 16 * jj + (lane & 15), lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = read_frag32(tA, 128 * g + 16 * i + (lane & 15), lane >> 4);
+      if (g == 0) { load_w(s + 2); load_a(s + 3); }
+      else { load_a(s + 3); load_w(s + 3); wait_tile(s + 1); }
+      SG_PS_SYNC();
+      // MFMA(s)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[jj], fa[i], acc[i][jj], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (g == 0) wait_tile(s + 1);
+      SG_PS_SYNC();
+    }
+    // ---- tile end ----
+    if (g == 0) SG_PS_SYNC();                               // align: every read of this tile's last K tile has retired
+    {
+      float* patch = reinterpret_cast<float*>(lds + ((s - 1) & 3) * TILE_B) + wave * 576;   // 8 rows x 68 floats (+pad) per wave
+      epilogue_store8<8, 4>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
+    }
+    cur = nxt; cur_end += nt;
+    if (j + 2 < my_tiles) nxt = make_src(j + 2);
+    SG_PS_SYNC();                                           // the ring slot used as patch may be refilled from here on
+    if (g == 1 && j + 1 < my_tiles) SG_PS_SYNC();           // re-stagger
+  }
+#undef SG_PS_SYNC
+}
+
+static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
+  const size_t lds = 4 * (256 + 256) * 32 * 2;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
+  const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+  hipLaunchKernelGGL(gemm_bf16_persist, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
+  return SG_OK;
+}
+
 static int g_gemm_config = -1;                             // -1 = pick per shape
 void set_gemm_config(int c) { g_gemm_config = c; }
 
@@ -755,7 +978,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   (void)csz;
   SG_REQUIRE(a.act >= 0 && a.act <= 2, "gemm_bf16: bad act %d", a.act);
   int cfg = g_gemm_config;
-  if (cfg < 0) cfg = (a.M >= 1024 && a.N >= 512) ? 7 : 4;  // small problems keep the 128x128 tile (more workgroups)
+  if (cfg < 0) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups)
   if (cfg > 0) {
     prof_begin(PROF_GEMM_BF16, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
     int rc;
@@ -767,6 +990,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
       case 5: rc = launch_ring<256, 128, 4, 2, 2>(a, vec, s); break;
       case 6: rc = launch_ring<128, 256, 2, 4, 3>(a, vec, s); break;
       case 7: rc = launch_pingpong(a, vec, s); break;
+      case 30: rc = (vec && a.K / 32 >= 4) ? launch_persist(a, s) : launch_pingpong(a, vec, s); break;
       case 9: rc = launch_ring<128, 256, 1, 4, 3, 0, 32>(a, vec, s); break;    // 72 KiB LDS: two workgroups per CU
       case 10: rc = launch_ring<256, 128, 4, 1, 3, 0, 32>(a, vec, s); break;
       case 8: rc = vec ? launch_pp32<0>(a, s) : launch_pingpong(a, vec, s); break;
