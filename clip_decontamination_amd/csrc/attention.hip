@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + h * 8);
     }
+    // Retire the Q loads HERE: otherwise the compiler's counted vmcnt in front of the first QK^T MFMA also waits (every iteration)
+    // for the K/V prefetch that was issued a few instructions earlier, exposing its full latency.
+#pragma unroll
+    for (int t = 0; t < TS; ++t)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[t][ks]));
 #pragma unroll
     for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
@@ -143,16 +149,40 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
 
       // ---- scores of the whole 64-key tile: S^T[key][query], 2 sub-blocks x KS k-steps -----------------------------
       f32x16 sacc[2];
+      {
+        bf16x8 kf[2][TS][C::KS];                           // all K fragments of the tile first: one exposed LDS latency, not eight
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+          for (int t = 0; t < TS; ++t)
 #pragma unroll
-        for (int t = 0; t < TS; ++t)
+            for (int ks = 0; ks < C::KS; ++ks)
+              kf[sub][t][ks] = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
 #pragma unroll
-          for (int ks = 0; ks < C::KS; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
-            sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], sacc[sub], 0, 0, 0);
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+#pragma unroll
+          for (int t = 0; t < TS; ++t)
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
+              sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][t][ks], qf[t][ks], sacc[sub], 0, 0, 0);
+        }
+      }
+      // (b) V^T fragments of the tile are fetched NOW (transposed LDS reads, lane 4q+p of a 16-lane group addresses row q,
+      // cols 4p..4p+3) so their latency hides under the softmax arithmetic below.
+      typedef __attribute__((ext_vector_type(8))) short short8_;
+      short8_ vfr[C::DVT][4];
+      if (do_pv) {
+#pragma unroll
+        for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const int key0 = f * 16 + 4 * h;
+            const bf16_t* p0 = sV + (key0 + qq) * C::V_LD + t * 32 + 16 * (g & 1) + 4 * pp;
+            const short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0));
+            const short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0 + 8 * C::V_LD));
+            vfr[t][f] = (short8_){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
       }
       // log2-domain scores for query q_glob (lane); key of (sub, r) = k0 + 32 sub + (r&3) + 8 (r>>2) + 4 h
@@ -209,19 +239,11 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
-        // V^T fragments by transposed LDS read: lane 4q+p of a 16-lane group addresses row q, cols 4p..4p+3
 #pragma unroll
         for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            const int key0 = f * 16 + 4 * h;
-            const bf16_t* p0 = sV + (key0 + qq) * C::V_LD + t * 32 + 16 * (g & 1) + 4 * pp;
-            const short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0));
-            const short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0 + 8 * C::V_LD));
-            typedef __attribute__((ext_vector_type(8))) short short8_;
-            short8_ vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[f], o_acc[t], 0, 0, 0);
-          }
+          for (int f = 0; f < 4; ++f)
+            o_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vfr[t][f]), pf[f], o_acc[t], 0, 0, 0);
       }
       if (has_next) {                                        // the other buffer was last read one iteration ago
         bf16_t* nK = sbuf + (cur ^ 1) * BUF;
