@@ -59,6 +59,8 @@ SIGNATURES = {
     "sg_postprocess": (I, [P, P, I, I, I, I, F, F, I, P, P, P]),
     "sg_outlier_scratch_bytes": (Z, [I, I, I]),
     "sg_outlier_suppress": (I, [P, P, P, I, I, I, I, I, F, P, P, P]),
+    "sg_cross_tile_scratch_bytes": (Z, [I, I, I, I, I]),
+    "sg_cross_tile_fusion": (I, [P, I, I, I, I, I, I, I, F, P, P]),
     "sg_weak_token_replace": (I, [P, P, I, I, I, I, I, P, P, P]),
     "sg_similarity_map": (I, [P, L, I, I, I, I, F, I, I, P, P, Z, P]),
     "sg_op_linear": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),

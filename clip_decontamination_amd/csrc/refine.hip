@@ -179,4 +179,146 @@ int attn_mode_enhance(float*, int64_t, int64_t, const float*, const float*, int,
   return fail(SG_ERR_INVALID, "self-attention enhancement mode='attention' is not built yet (SURVEY.md §8f rank 3)");
 }
 
+// ---- cross-tile boundary fusion (reference cross_tile_fusion.py:24-320; unwired there) -----------------------------
+// Tiles arrive in raster order, so only the 'top' and 'left' directions ever find a cached neighbour.  The reference's
+// strip extraction aliases (row strips are views, column strips are copies), which fixes the data flow restated in
+// oracle/refine.py::CrossTileFusionOracle:
+//   left  : fuse(ORIGINAL left columns of the tile, ORIGINAL right columns of the left neighbour)   -> columns [0,bw)
+//   top   : fuse(ORIGINAL top rows of the tile, FINAL bottom rows of the upper neighbour)            -> rows [0,bw)
+//           (final = original with that neighbour's own left result in columns [0,bw)); the left result wins the corner.
+// Neither depends on another tile's top result (gh >= 2 bw), so every strip of a scene is fused in parallel:
+// one workgroup per (tile, direction) writes its strip to scratch, a second launch scatters.
+constexpr int CTF_MAX_STRIP = 128;
+
+struct StripView {           // strip element e (0..len) -> token row pointer
+  const float* base; int a_stride, b_stride, b_len, offset;   // token index = offset + (e / b_len) * a_stride + (e % b_len) * b_stride
+  __device__ __forceinline__ int tok(int e) const { return offset + (e / b_len) * a_stride + (e % b_len) * b_stride; }
+};
+
+__global__ __launch_bounds__(256) void ctf_fuse_kernel(const float* __restrict__ tokens, const float* __restrict__ left_scratch, int hg,
+                                                       int wg, int gh, int gw, int C, int bw, int mode, float strength, int pass,
+                                                       float* __restrict__ out_scratch) {
+  extern __shared__ float sm[];
+  const int tile = blockIdx.x, hi = tile / wg, wi = tile % wg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = gh * gw;
+  const bool is_left = pass == 0;
+  if (is_left ? (wi == 0) : (hi == 0)) return;
+  const int S = is_left ? gh * bw : bw * gw;                  // both strips of a pair have the same length
+  float* sim = sm;                                            // [S][L2]   L2 = S (weighted) or 2S (attention)
+  const int L2 = mode == 0 ? S : 2 * S;
+  float* rn_cur = sm + S * L2;                                // [S] norms / row scalars
+  float* rn_nbr = rn_cur + S;
+  const float* cur_t = tokens + (int64_t)tile * n * C;
+  const int nb_tile = is_left ? tile - 1 : tile - wg;
+  const float* nbr_t = tokens + (int64_t)nb_tile * n * C;
+  // element e of the current / neighbour strip -> patch index inside its tile
+  auto cur_idx = [&](int e) { return is_left ? (e / bw) * gw + (e % bw) : e; };                        // left cols | top rows
+  auto nbr_idx = [&](int e) { return is_left ? (e / bw) * gw + (gw - bw) + (e % bw) : (gh - bw) * gw + e; };   // right cols | bottom rows
+  // the upper neighbour's bottom rows are FINAL: its own left result replaces columns [0,bw)
+  auto nbr_row = [&](int e) -> const float* {
+    if (!is_left && (nb_tile % wg) > 0) {
+      const int col = e % gw, row = gh - bw + e / gw;
+      if (col < bw) return left_scratch + ((int64_t)nb_tile * gh * bw + row * bw + col) * C;
+    }
+    return nbr_t + (int64_t)nbr_idx(e) * C;
+  };
+  const float eps = 1e-6f;
+  for (int e = wave; e < S; e += 4) {                         // norms (weighted mode)
+    const float* x = cur_t + (int64_t)cur_idx(e) * C; const float* y = nbr_row(e);
+    float a = 0.f, b2 = 0.f;
+    for (int c = lane; c < C; c += 64) { a += x[c] * x[c]; b2 += y[c] * y[c]; }
+    a = wave_sum(a); b2 = wave_sum(b2);
+    if (lane == 0) { rn_cur[e] = sqrtf(a) + eps; rn_nbr[e] = sqrtf(b2) + eps; }
+  }
+  __syncthreads();
+  for (int p = wave; p < S * L2; p += 4) {                    // similarity / score matrix, one wave per entry
+    const int i = p / L2, j = p % L2;
+    const float* x = cur_t + (int64_t)cur_idx(i) * C;
+    const float* y = (mode == 1 && j < S) ? cur_t + (int64_t)cur_idx(j) * C : nbr_row(mode == 1 ? j - S : j);
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d += x[c] * y[c];
+    d = wave_sum(d);
+    if (lane == 0) sim[p] = mode == 0 ? d / (rn_cur[i] * rn_nbr[j]) : d / sqrtf((float)C);
+  }
+  __syncthreads();
+  for (int i = tid; i < S; i += 256) {                        // per-row weights
+    float* r = sim + i * L2;
+    if (mode == 0) {
+      float mean = 0.f;
+      for (int j = 0; j < L2; ++j) mean += r[j];
+      mean /= (float)L2;
+      float var = 0.f;
+      for (int j = 0; j < L2; ++j) var += (r[j] - mean) * (r[j] - mean);
+      const float thr = mean + sqrtf(var / (float)(L2 - 1));  // torch.std: unbiased
+      float msum = 0.f, wsum = 0.f;
+      for (int j = 0; j < L2; ++j) { const float mg = fmaxf(r[j] - thr, 0.f); msum += mg; r[j] = mg * mg; wsum += mg * mg; }
+      wsum += eps;
+      for (int j = 0; j < L2; ++j) r[j] /= wsum;
+      rn_cur[i] = strength * fminf(fmaxf(msum / (float)L2, 0.f), 1.f);       // blend factor of the row
+    } else {
+      float mx = -INFINITY, sum = 0.f;
+      for (int j = 0; j < L2; ++j) mx = fmaxf(mx, r[j]);
+      for (int j = 0; j < L2; ++j) { r[j] = expf(r[j] - mx); sum += r[j]; }
+      for (int j = 0; j < L2; ++j) r[j] /= sum;
+      rn_cur[i] = strength;
+    }
+  }
+  __syncthreads();
+  float* dst = out_scratch + (int64_t)tile * S * C;
+  for (int p = tid; p < S * C; p += 256) {                    // blended strip
+    const int i = p / C, c = p % C;
+    const float* w = sim + i * L2;
+    float agg = 0.f;
+    if (mode == 1) for (int j = 0; j < S; ++j) agg += w[j] * cur_t[(int64_t)cur_idx(j) * C + c];
+    for (int j = 0; j < S; ++j) agg += w[(mode == 1 ? S : 0) + j] * nbr_row(j)[c];
+    const float sfac = rn_cur[i];
+    dst[p] = cur_t[(int64_t)cur_idx(i) * C + c] * (1.f - sfac) + agg * sfac;
+  }
+}
+
+__global__ void ctf_apply_kernel(float* __restrict__ tokens, const float* __restrict__ left_scratch, const float* __restrict__ top_scratch,
+                                 int hg, int wg, int gh, int gw, int C, int bw) {
+  const int tile = blockIdx.y, hi = tile / wg, wi = tile % wg;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = gh * gw;
+  if (i >= (int64_t)n * C) return;
+  const int c = (int)(i % C), p = (int)(i / C), row = p / gw, col = p % gw;
+  if (wi > 0 && col < bw) tokens[(int64_t)tile * n * C + i] = left_scratch[((int64_t)tile * gh * bw + row * bw + col) * C + c];
+  else if (hi > 0 && row < bw) tokens[(int64_t)tile * n * C + i] = top_scratch[((int64_t)tile * bw * gw + row * gw + col) * C + c];
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" size_t sg_cross_tile_scratch_bytes(int T, int gh, int gw, int C, int bw) {
+  return ((size_t)T * gh * bw * C + (size_t)T * bw * gw * C) * sizeof(float) + 512;
+}
+
+extern "C" int sg_cross_tile_fusion(float* tokens, int hg, int wg, int gh, int gw, int C, int bw, int mode, float strength, void* scratch,
+                                    sg_stream st) {
+  SG_REQUIRE(tokens && scratch, "sg_cross_tile_fusion: null pointer");
+  SG_REQUIRE(hg > 0 && wg > 0 && gh > 0 && gw > 0 && C > 0 && bw > 0, "sg_cross_tile_fusion: bad shape");
+  SG_REQUIRE(gh >= 2 * bw && gw >= 2 * bw, "sg_cross_tile_fusion: patch grid %dx%d too small for boundary width %d", gh, gw, bw);
+  SG_REQUIRE(gh * bw <= CTF_MAX_STRIP && gw * bw <= CTF_MAX_STRIP, "sg_cross_tile_fusion: strips longer than %d tokens", CTF_MAX_STRIP);
+  SG_REQUIRE(mode == 0 || mode == 1, "sg_cross_tile_fusion: mode must be 0 (weighted) or 1 (attention)");
+  hipStream_t s = as_stream(st);
+  const int T = hg * wg;
+  float* left = reinterpret_cast<float*>(scratch);
+  float* top = left + (size_t)T * gh * bw * C;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int S = pass == 0 ? gh * bw : bw * gw;
+    const size_t lds = ((size_t)S * (mode == 0 ? S : 2 * S) + 2 * S) * sizeof(float);
+    if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ctf_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ctf_fuse_kernel, dim3(T), dim3(256), lds, s, tokens, left, hg, wg, gh, gw, C, bw, mode, strength, pass, pass == 0 ? left : top);
+    SG_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(ctf_apply_kernel, dim3((unsigned)cdiv((int64_t)gh * gw * C, 256), (unsigned)T), dim3(256), 0, s, tokens, left, top, hg, wg, gh, gw, C, bw);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+namespace sg {
+
 }  // namespace sg

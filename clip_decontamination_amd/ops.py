@@ -209,3 +209,18 @@ def adaptive_conv(inp, filters):
     out = torch.empty(B, Cc, h, w, dtype=torch.float32, device=inp.device)
     check(lib.sg_adaptive_conv(ptr(inp), ptr(filters), B, Cc, h, w, d, ptr(out), stream_ptr()), "sg_adaptive_conv")
     return out
+
+
+def cross_tile_fusion(tokens, hg: int, wg: int, gh: int, gw: int, boundary_width: int = 2, fusion_mode: str = "weighted",
+                      fusion_strength: float = 0.3):
+    """tokens [hg*wg, gh*gw, C] (tiles in raster order) -> fused copy (reference cross_tile_fusion.py, B=1 tile-by-tile semantics)."""
+    lib = _lib.load()
+    tokens = _f32(tokens).clone()
+    _require_gpu(tokens)
+    T, n, Cc = tokens.shape
+    assert T == hg * wg and n == gh * gw
+    buf = scratch(lib.sg_cross_tile_scratch_bytes(T, gh, gw, Cc, boundary_width), tokens.device)
+    sp, _ = _aligned(buf)
+    check(lib.sg_cross_tile_fusion(ptr(tokens), hg, wg, gh, gw, Cc, boundary_width, 0 if fusion_mode == "weighted" else 1,
+                                   float(fusion_strength), sp, stream_ptr()), "sg_cross_tile_fusion")
+    return tokens

@@ -42,7 +42,7 @@ class SegPipeline:
     def __init__(self, net: HipCLIP, text: torch.Tensor, query_idx: torch.Tensor, model_type: str = "SegEarth",
                  ignore_residual: bool = True, cls_token_lambda: float = 0.0, global_debias_factor: float = 0.0,
                  logit_scale: float = 50.0, prob_thd: float = 0.0, bg_idx: int = 0, apply_similarity_enhancement: bool = False,
-                 upsampler=None, tiles_per_launch: int = 32):
+                 upsampler=None, tiles_per_launch: int = 32, cross_tile_fusion: Optional[dict] = None):
         self.net = net
         self.visual = net.visual
         self.device = self.visual.device
@@ -58,10 +58,12 @@ class SegPipeline:
         self.apply_similarity_enhancement = apply_similarity_enhancement
         self.upsampler = upsampler
         self.tiles_per_launch = int(tiles_per_launch)
+        # opt-in: the reference ships CrossTileFusion but never calls it; kwargs of its constructor
+        self.cross_tile_fusion = cross_tile_fusion
 
     # -- per-tile logits -----------------------------------------------------------------------------------
     def tile_logits(self, scene: torch.Tensor, windows: Sequence[Tuple[int, int, int, int]], tile_hw: Tuple[int, int],
-                    scene_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    scene_index: Optional[torch.Tensor] = None, grid_of_tiles: Optional[Tuple[int, int]] = None) -> torch.Tensor:
         """-> [T, Q, gh, gw] patch-grid logits (or [T, Q, H', W'] per-pixel logits with the JBU upsampler)."""
         v = self.visual
         P = v.cfg.patch
@@ -71,6 +73,24 @@ class SegPipeline:
         opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement)
         win = torch.tensor(list(windows), dtype=torch.int32, device=self.device).reshape(-1, 4)
         outs = []
+        fuse = self.cross_tile_fusion is not None and grid_of_tiles is not None and grid_of_tiles[0] * grid_of_tiles[1] > 1
+        if fuse:
+            # boundary fusion couples neighbouring tiles: run the tower over the whole scene first, fuse, then the head
+            cls_all, tok_all = [], []
+            for i in range(0, win.shape[0], self.tiles_per_launch):
+                si = None if scene_index is None else scene_index[i:i + self.tiles_per_launch]
+                c_, t_ = v.forward_tiles(scene, win[i:i + self.tiles_per_launch], tile_hw, opts, si)
+                cls_all.append(c_); tok_all.append(t_)
+            tok = ops.cross_tile_fusion(torch.cat(tok_all, 0), grid_of_tiles[0], grid_of_tiles[1], gh, gw,
+                                        self.cross_tile_fusion.get("cache_boundary_width", 2),
+                                        self.cross_tile_fusion.get("fusion_mode", "weighted"),
+                                        self.cross_tile_fusion.get("fusion_strength", 0.3))
+            cls = None if cls_all[0] is None else torch.cat(cls_all, 0)
+            if self.upsampler is not None:
+                raise NotImplementedError("cross-tile fusion together with the JBU upsampler is not wired")
+            lg = ops.cosine_logits(tok, cls, self.text, self.global_debias_factor if cls is not None else 0.0,
+                                   self.cls_token_lambda if cls is not None else 0.0)
+            return lg.reshape(win.shape[0], self.num_queries, gh, gw)
         for i in range(0, win.shape[0], self.tiles_per_launch):
             w = win[i:i + self.tiles_per_launch]
             si = None if scene_index is None else scene_index[i:i + self.tiles_per_launch]
@@ -102,8 +122,12 @@ class SegPipeline:
         world, rank = 1, 0
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+        hg = max(H - crop[0] + stride[0] - 1, 0) // stride[0] + 1
+        wg = max(W - crop[1] + stride[1] - 1, 0) // stride[1] + 1
+        if world > 1 and self.cross_tile_fusion is not None:
+            raise NotImplementedError("cross-tile fusion under tile sharding needs a strip exchange between ranks (SURVEY.md §8e); not built")
         if world == 1:
-            tl = self.tile_logits(scene, wins, tile_hw)
+            tl = self.tile_logits(scene, wins, tile_hw, grid_of_tiles=(hg, wg))
         else:
             tl = self.gather_tile_logits(scene, wins, tile_hw, world, rank, group)
         win_dev = torch.tensor(wins, dtype=torch.int32, device=self.device)

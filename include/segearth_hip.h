@@ -162,6 +162,12 @@ int sg_postprocess(const float* logits, const int32_t* query_idx, int Q, int K, 
 size_t sg_outlier_scratch_bytes(int B, int D, int k);
 int sg_outlier_suppress(float* feats, const float* attn_cls, const float* attn_diag, int B, int gh, int gw, int D,
                         int top_k, float contamination_temp, int32_t* out_idx, void* scratch, sg_stream s);
+/* sg_cross_tile_fusion replaces CrossTileFusion.forward applied to every tile of a scene in raster order
+ * (cross_tile_fusion.py:290-320; 'weighted' :185-236 adaptive branch, 'attention' :143-183).  The reference never calls the
+ * module (dead code); the semantics are those of running it tile by tile with B=1 (oracle/refine.py).
+ *   tokens [hg*wg, gh*gw, C] f32 patch tokens of the scene's tiles, updated in place; mode 0 = weighted, 1 = attention. */
+size_t sg_cross_tile_scratch_bytes(int T, int gh, int gw, int C, int bw);
+int sg_cross_tile_fusion(float* tokens, int hg, int wg, int gh, int gw, int C, int bw, int mode, float strength, void* scratch, sg_stream s);
 /* SelfAttentionEnhancementModule feature mode (self_attention_enhancement.py:71-150,247-324) */
 int sg_weak_token_replace(float* feats, const float* attn_diag, int B, int gh, int gw, int D, int top_k,
                           int32_t* out_idx, void* scratch, sg_stream s);

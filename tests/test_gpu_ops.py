@@ -297,3 +297,25 @@ def test_global_debias_and_extract_tiles(ops):
     sim = ((t / t.norm(dim=-1, keepdim=True)) * (c / c.norm(dim=-1, keepdim=True)).unsqueeze(1)).sum(-1)
     ref = t - c.unsqueeze(1) * (sim.unsqueeze(-1) * 0.2)
     assert (out.cpu() - ref).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["weighted", "attention"])
+def test_cross_tile_fusion_matches_reference_fixture(ops, golden, mode):
+    """Fixture: the reference CrossTileFusion module run tile by tile (raster order) on a 2x3 scene."""
+    g = golden("refine")
+    tiles = torch.from_numpy(g["ctf_tiles"])                   # [2,3,1,36,16]
+    hg, wg = tiles.shape[:2]
+    tok = tiles.reshape(hg * wg, 36, 16)
+    out = ops.cross_tile_fusion(tok.to(DEV), hg, wg, 6, 6, 2, mode, 0.3)
+    ref = torch.from_numpy(g[f"ctf_{mode}"]).reshape(hg * wg, 36, 16)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+def test_cross_tile_fusion_larger_grid_vs_oracle(ops):
+    hg, wg, gp, C = 3, 4, 9, 40
+    tok = rnd(hg * wg, gp * gp, C, seed=3)
+    for mode in ("weighted", "attention"):
+        o = OR.CrossTileFusionOracle(mode, 2, 0.5)
+        ref = torch.stack([o(tok[t:t + 1].clone(), t // wg, t % wg, gp, gp)[0] for t in range(hg * wg)], 0)
+        out = ops.cross_tile_fusion(tok.to(DEV), hg, wg, gp, gp, 2, mode, 0.5)
+        assert (out.cpu() - ref).abs().max().item() < 3e-5
