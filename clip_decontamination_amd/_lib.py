@@ -66,6 +66,7 @@ SIGNATURES = {
     "sg_op_linear": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),
     "sg_gemm_bf16_raw": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "sg_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
+    "sg_op_attention_scratch_bytes": (Z, [I, I, I, I, I]),
     "sg_op_attention": (I, [P, I, I, I, I, I, P, F, P, P, P, I, P, Z, P]),
     "sg_adaptive_conv": (I, [P, P, I, I, I, I, I, P, P]),
     "sg_jbu_create": (I, [C.POINTER(P), I, I, I]),

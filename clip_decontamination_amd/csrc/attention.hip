@@ -127,12 +127,15 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
     // GENERIC: the additive bias (similarity map) of the NEXT key tile is fetched one tile ahead -- 32 coalesced dword loads per
     // lane (the map is symmetric, so it is read as bias[key][query] with the queries on the lanes)
     float bnext[GENERIC ? 32 : 1];
+    const float bias_rn = (GENERIC && a.bias_rn) ? a.bias_rn[((int64_t)b * a.H + hd) * a.N + q_ld] : 1.f;
     auto fetch_bias = [&](int kbase) {
       if (GENERIC && a.bias) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-          bnext[i] = (key >= 1 && key < a.N && q_ld >= 1) ? a.bias[((int64_t)b * n + (key - 1)) * n + (q_ld - 1)] : 0.f;
+          float bvv = (key >= 1 && key < a.N && q_ld >= 1) ? a.bias[(int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1)] : 0.f;
+          if (a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
+          bnext[i] = bvv;
         }
       }
     };

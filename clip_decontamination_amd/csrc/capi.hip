@@ -83,15 +83,19 @@ namespace sg {
 static int expected_tensors(const sg_vit_desc& d) { return 8 + 12 * d.layers; }
 
 // ---- variants of the last-block attention: which (Q,K) terms, summed or not ---------------------------------------
-struct Variant { int n_terms, sum_scores, qsel[3], ksel[3]; float scale_mul; int resoftmax; };   // sel: 0=q 1=k 2=v
+struct Variant { int n_terms, sum_scores, qsel[3], ksel[3]; float scale_mul; int resoftmax; int gauss; };   // sel: 0=q 1=k 2=v; gauss: 1 plain omega, 2 omega*|q||k|*scale
 static bool variant_of(int model_type, Variant& v) {
   switch (model_type) {
-    case SG_VANILLA:      v = {1, 0, {0, 0, 0}, {1, 0, 0}, 1.f, 0}; return true;
-    case SG_CLEARCLIP:    v = {1, 0, {0, 0, 0}, {0, 0, 0}, 1.f, 0}; return true;
-    case SG_SCLIP:        v = {2, 0, {0, 1, 0}, {0, 1, 0}, 1.f, 0}; return true;
-    case SG_SEGEARTH:     v = {3, 0, {0, 1, 2}, {0, 1, 2}, 1.f, 0}; return true;
-    case SG_SFP:          v = {2, 1, {0, 1, 0}, {0, 1, 0}, 0.5f, 0}; return true;
-    case SG_EXPERIMENTAL: v = {2, 1, {1, 0, 0}, {1, 0, 0}, 1.f, 1}; return true;
+    case SG_VANILLA:      v = {1, 0, {0, 0, 0}, {1, 0, 0}, 1.f, 0, 0}; return true;
+    case SG_CLEARCLIP:    v = {1, 0, {0, 0, 0}, {0, 0, 0}, 1.f, 0, 0}; return true;
+    case SG_SCLIP:        v = {2, 0, {0, 1, 0}, {0, 1, 0}, 1.f, 0, 0}; return true;
+    case SG_SEGEARTH:     v = {3, 0, {0, 1, 2}, {0, 1, 2}, 1.f, 0, 0}; return true;
+    case SG_SFP:          v = {2, 1, {0, 1, 0}, {0, 1, 0}, 0.5f, 0, 0}; return true;
+    case SG_EXPERIMENTAL: v = {2, 1, {1, 0, 0}, {1, 0, 0}, 1.f, 1, 0}; return true;
+    // Gaussian-window variants (transformer.py:909-932): the similarity map is NOT applied on these paths in the reference
+    case SG_NACLIP:       v = {1, 0, {1, 0, 0}, {1, 0, 0}, 1.f, 0, 1}; return true;      // k k^T * scale + omega
+    case SG_NONLY:        v = {1, 0, {0, 0, 0}, {1, 0, 0}, 0.f, 0, 2}; return true;      // omega * scale * |q_i| |k_j| only
+    case SG_GAV:          v = {1, 0, {0, 0, 0}, {1, 0, 0}, 1.f, 0, 2}; return true;      // q k^T * scale + omega * scale * |q_i| |k_j|
     default: return false;
   }
 }
@@ -99,13 +103,13 @@ static bool variant_of(int model_type, Variant& v) {
 // Generic multi-term attention in either precision.  Element (b, t, h, d) of a Q/K operand lives at
 // p + b*sb + t*st + h*dh + d (elements of the compute dtype); V has its own strides.
 // f32: materialised scores/probs in `scores`/`probs` ([B*H,N,N] each).  bf16: fused kernel.
-struct AttnBuffers { float* scores; float* probs; float* lse; float* lse1; };
+struct AttnBuffers { float* scores; float* probs; float* lse; float* lse1; float* omega; float* qnorm; float* knorm; };
 struct AttnSpec {
   const void* q[3]; const void* k[3]; int64_t sb, st;
   const void* v; int64_t v_sb, v_st;
   int n_terms, sum_scores, resoftmax;
   float scale; const float* scale_per_image;
-  const float* bias; float bias_w;
+  const float* bias; float bias_w; int64_t bias_bstride; const float* bias_rn; const float* bias_cn;
   float out_scale;
   void* ctx; int64_t ctx_sb, ctx_st;
   bool want_lse;
@@ -124,7 +128,7 @@ static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int 
       SG_TRY(attention_bf16(p, s));
       a.resoftmax = 1; a.lse_in = buf.lse1;
     }
-    a.bias = sp.bias; a.bias_w = sp.bias_w; a.ctx = (bf16_t*)sp.ctx; a.lse_out = sp.want_lse ? buf.lse : nullptr;
+    a.bias = sp.bias; a.bias_w = sp.bias_w; a.bias_bstride = sp.bias_bstride; a.bias_rn = sp.bias_rn; a.bias_cn = sp.bias_cn; a.ctx = (bf16_t*)sp.ctx; a.lse_out = sp.want_lse ? buf.lse : nullptr;
     return attention_bf16(a, s);
   }
   const int64_t NN = (int64_t)N * N;
@@ -140,12 +144,12 @@ static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int 
   const int64_t rows = (int64_t)B * H * N;
   if (sp.sum_scores) {
     for (int t = 0; t < sp.n_terms; ++t) SG_TRY(scores_of(t, t > 0));
-    SG_TRY(softmax_rows(buf.scores, N, rows, N, H, sp.scale_per_image, sp.scale, sp.bias, sp.bias_w, sp.resoftmax ? 1 : 0, 0,
+    SG_TRY(softmax_rows(buf.scores, N, rows, N, H, sp.scale_per_image, sp.scale, sp.bias, sp.bias_w, sp.bias_bstride, sp.bias_rn, sp.bias_cn, sp.resoftmax ? 1 : 0, 0,
                         buf.probs, sp.want_lse ? buf.lse : nullptr, s));
   } else {
     for (int t = 0; t < sp.n_terms; ++t) {
       SG_TRY(scores_of(t, false));
-      SG_TRY(softmax_rows(buf.scores, N, rows, N, H, sp.scale_per_image, sp.scale, sp.bias, sp.bias_w, 0, t > 0, buf.probs,
+      SG_TRY(softmax_rows(buf.scores, N, rows, N, H, sp.scale_per_image, sp.scale, sp.bias, sp.bias_w, sp.bias_bstride, sp.bias_rn, sp.bias_cn, 0, t > 0, buf.probs,
                           (sp.want_lse && t == 0) ? buf.lse : nullptr, s));
     }
   }
@@ -170,7 +174,19 @@ static int run_attention(bool bf16, const void* qkv, int B, int N, int D, int H,
   sp.st = sp.v_st = 3 * (int64_t)D; sp.sb = sp.v_sb = (int64_t)N * 3 * D;
   sp.n_terms = v.n_terms; sp.sum_scores = v.sum_scores; sp.resoftmax = v.resoftmax;
   sp.scale = v.scale_mul / sqrtf((float)dh); sp.scale_per_image = scale_per_image;
-  sp.bias = sim; sp.bias_w = sim_w; sp.out_scale = 1.f;
+  sp.bias = sim; sp.bias_w = sim_w; sp.bias_bstride = (int64_t)(N - 1) * (N - 1); sp.out_scale = 1.f;
+  if (v.gauss) {
+    const int gside = (int)lroundf(sqrtf((float)(N - 1)));                 // the reference assumes a square grid here (transformer.py:912)
+    SG_REQUIRE(gside * gside == N - 1, "Gaussian-window attention needs a square patch grid (N-1 = %d)", N - 1);
+    SG_REQUIRE(buf.omega && buf.qnorm && buf.knorm, "Gaussian-window attention: scratch missing");
+    SG_TRY(gaussian_bias(gside, gside, 1.0f, buf.omega, s));
+    sp.bias = buf.omega; sp.bias_bstride = 0; sp.bias_w = 1.f;
+    if (v.gauss == 2) {
+      SG_TRY(head_norms(sp.q[0], bf16, sp.sb, sp.st, B, N, H, dh, buf.qnorm, s));
+      SG_TRY(head_norms(sp.k[0], bf16, sp.sb, sp.st, B, N, H, dh, buf.knorm, s));
+      sp.bias_rn = buf.qnorm; sp.bias_cn = buf.knorm; sp.bias_w = 1.0f / sqrtf((float)dh);
+    }
+  }
   sp.ctx = ctx; sp.ctx_sb = (int64_t)N * D; sp.ctx_st = D; sp.want_lse = want_lse;
   return attn_generic(bf16, sp, B, N, H, dh, buf, s);
 }
@@ -226,6 +242,7 @@ struct Plan {
   void *patchA; float* patchOut; float* pos_r; float* x; void* xn; void* qkv; void* ctx; void* hbuf; void* xhat; float* sim;
   float *lse, *lse1, *attn_cls, *attn_diag, *out_last, *y; int32_t *idx_out, *idx_sa; void* refine_scratch;
   float *scores, *probs;
+  float *omega, *qnorm, *knorm;
   // GEM
   float* x_gem; void* gnorm[3]; void* gatt[3]; float* inv_temp; float* gem_out; void* ctx2;
 };
@@ -260,6 +277,10 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.refine_scratch = b.take(refine_scratch_bytes(B, d.width, kmax > 0 ? kmax : 1));
   p.scores = p.probs = nullptr;
   if (!c->bf16) { p.scores = b.get<float>((size_t)B * d.heads * N * N); p.probs = b.get<float>((size_t)B * d.heads * N * N); }
+  p.omega = p.qnorm = p.knorm = nullptr;
+  if (o->model_type == SG_NACLIP || o->model_type == SG_NONLY || o->model_type == SG_GAV) {
+    p.omega = b.get<float>((size_t)n * n); p.qnorm = b.get<float>((size_t)B * d.heads * N); p.knorm = b.get<float>((size_t)B * d.heads * N);
+  }
   p.x_gem = nullptr;
   if (o->model_type == SG_GEM) {
     p.x_gem = b.get<float>(R * d.width);
@@ -465,7 +486,7 @@ static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
   const sg_vit_desc& d = c->d;
   const int D = d.width, H = d.heads;
   const int64_t R = (int64_t)B * N;
-  AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1};
+  AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1, p.omega, p.qnorm, p.knorm};
   SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
   SG_TRY(linear(c->bf16, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
   SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s));
@@ -526,12 +547,12 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
       SG_TRY(similarity_from_xhat(c->bf16, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s));
     // ---- last block: self-self attention on ln_1(x), no residual / MLP when ignore_residual (transformer.py:627-643) ----
     const LayerW& LL = c->layers[L - 1];
-    AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1};
+    AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1, p.omega, p.qnorm, p.knorm};
     SG_TRY(layernorm(p.x, D, LL.ln1_g, LL.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
     SG_TRY(linear(c->bf16, p.xn, D, LL.w_qkv, LL.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
     const void* ctx = p.ctx; int64_t ctx_ld = D;
     if (o->model_type == SG_MASKCLIP) { ctx = (const char*)p.qkv + (size_t)2 * D * c->esz; ctx_ld = 3 * D; }   // identity attention: ctx = v
-    else SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, o->model_type, o->similarity_enabled ? p.sim : nullptr, o->similarity_weight,
+    else SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, o->model_type, (o->similarity_enabled && o->model_type < SG_NACLIP) ? p.sim : nullptr, o->similarity_weight,
                               nullptr, p.ctx, false, ab, s));
     SG_TRY(linear(c->bf16, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
     if (!o->ignore_residual) SG_TRY(mlp_block(c, LL, p.out_last, p, R, s));
@@ -565,7 +586,7 @@ static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan&
   const int first = L - (o->gem_depth - 1);
   const bool bf = c->bf16;
   SG_HIP(hipMemcpyAsync(p.x_gem, p.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
-  AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1};
+  AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1, nullptr, nullptr, nullptr};
   for (int i = first; i < L; ++i) {
     const LayerW& LW = c->layers[i];
     // ln_1(x): f32 copy for the temperature (mean token norm, gem_utils.py:79-81), compute-dtype copy for the GEMM
@@ -625,6 +646,14 @@ extern "C" int sg_op_linear(const float* A, const float* W, const float* bias, c
   return linear(true, a16, Kp, w16, bias, residual, C, N, true, M, N, Kp, act, s);
 }
 
+extern "C" size_t sg_op_attention_scratch_bytes(int B, int N, int D, int H, int precision) {
+  const size_t R = (size_t)B * N;
+  size_t b = 4 * 256 + 2 * align_up((size_t)B * H * N * 4, 256) + align_up((size_t)(N - 1) * (N - 1) * 4, 256) + 2 * align_up((size_t)B * H * N * 4, 256);
+  if (precision == SG_PREC_BF16) b += align_up(R * 3 * D * 2, 256) + align_up(R * D * 2, 256);
+  else b += 2 * align_up((size_t)B * H * N * N * 4, 256);
+  return b + 4096;
+}
+
 extern "C" int sg_op_attention(const float* qkv, int B, int N, int D, int H, int variant, const float* sim, float sim_weight, float* ctx,
                                float* attn_cls, float* attn_diag, int precision, void* scratch, size_t scratch_bytes, sg_stream st) {
   SG_REQUIRE(qkv && ctx && scratch, "sg_op_attention: null pointer");
@@ -635,6 +664,7 @@ extern "C" int sg_op_attention(const float* qkv, int B, int N, int D, int H, int
   Bump b(scratch, scratch_bytes, false);
   AttnBuffers ab{};
   ab.lse = b.get<float>((size_t)B * H * N); ab.lse1 = b.get<float>((size_t)B * H * N);
+  ab.omega = b.get<float>((size_t)(N - 1) * (N - 1)); ab.qnorm = b.get<float>((size_t)B * H * N); ab.knorm = b.get<float>((size_t)B * H * N);
   void* qkv_c = (void*)qkv; void* ctx_c = ctx;
   if (bf) { qkv_c = b.take((size_t)R * 3 * D * 2); ctx_c = b.take((size_t)R * D * 2); }
   else { ab.scores = b.get<float>((size_t)B * H * N * N); ab.probs = b.get<float>((size_t)B * H * N * N); }

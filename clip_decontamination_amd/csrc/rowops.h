@@ -15,7 +15,10 @@ int transpose_pack(const float* src, int rows, int cols, void* dst, int to_bf16,
 int l2norm_rows(const void* x, int x_bf16, int64_t so, int64_t si, int inner, void* y, int y_bf16, int64_t yo, int64_t yi,
                 int64_t rows, int D, float eps, hipStream_t s);
 int softmax_rows(const float* scores, int64_t ld, int64_t rows, int N, int H, const float* scale_per_image, float scale,
-                 const float* bias, float bias_w, int mode, int accumulate, float* out, float* lse, hipStream_t s);
+                 const float* bias, float bias_w, int64_t bias_bstride, const float* bias_rn, const float* bias_cn, int mode,
+                 int accumulate, float* out, float* lse, hipStream_t s);
+int gaussian_bias(int gh, int gw, float std, float* omega, hipStream_t s);
+int head_norms(const void* x, int is_bf16, int64_t sb, int64_t st, int B, int N, int H, int dh, float* out, hipStream_t s);
 int axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s);
 int gem_inv_temp(const float* x, int B, int N, int D, float scale, float* out, hipStream_t s);
 
@@ -32,7 +35,9 @@ struct AttnArgs {
   int n_terms, sum_scores;
   int B, N, H, dh;
   float scale; const float* scale_per_image;  // per-image scale overrides `scale` when non-null (GEM inv_temp)
-  const float* bias; float bias_w;          // [B, N-1, N-1] symmetric, or null
+  const float* bias; float bias_w;          // [B, N-1, N-1] symmetric, or null; batch stride bias_bstride (0 = shared by all images)
+  int64_t bias_bstride;
+  const float* bias_rn; const float* bias_cn; // optional [B,H,N] row / column factors of the bias (NOnly / GAV: |q_i|, |k_j|)
   int resoftmax;                            // 'Experimental': softmax(softmax(score) + bias_w*bias); needs lse_in
   const float* lse_in;                      // [B,H,N] log-sum-exp of the first softmax (resoftmax)
   float* lse_out;                           // [B,H,N] or null; when ctx == null only the LSE pass runs

@@ -258,8 +258,9 @@ int l2norm_rows(const void* x, int x_bf16, int64_t so, int64_t si, int inner, vo
 // out (+)= p.  lse (optional) receives log-sum-exp of (scale*s [+ w*bias]) for mode 0.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ scores, int64_t ld, int64_t rows, int N, int H,
                                                            const float* __restrict__ scale_per_image, float scale,
-                                                           const float* __restrict__ bias, float bias_w, int mode,
-                                                           int accumulate, float* __restrict__ out, float* __restrict__ lse) {
+                                                           const float* __restrict__ bias, float bias_w, int64_t bias_bstride,
+                                                           const float* __restrict__ bias_rn, const float* __restrict__ bias_cn,
+                                                           int mode, int accumulate, float* __restrict__ out, float* __restrict__ lse) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -269,18 +270,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   const float* sr = scores + row * ld;
   float* orow = out + row * ld;
   const int n = N - 1;
-  const float* brow = (bias && i > 0) ? bias + ((int64_t)b * n + (i - 1)) * n : nullptr;   // sim[b, i-1, :]
+  const float* brow = (bias && i > 0) ? bias + b * bias_bstride + (int64_t)(i - 1) * n : nullptr;   // bias[b, i-1, :]
+  const int hd = (int)((row / N) % H);
+  const float* cn = bias_cn ? bias_cn + (b * H + hd) * (int64_t)N : nullptr;
+  if (bias_rn) bias_w *= bias_rn[(b * H + hd) * (int64_t)N + i];
   float mx = -INFINITY;
   for (int j = lane; j < N; j += 64) {
     float v = sr[j] * sc;
-    if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1];
+    if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     mx = fmaxf(mx, v);
   }
   mx = wave_max(mx);
   float sum = 0.f;
   for (int j = lane; j < N; j += 64) {
     float v = sr[j] * sc;
-    if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1];
+    if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     sum += expf(v - mx);
   }
   sum = wave_sum(sum);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   if (mode == 0) {
     for (int j = lane; j < N; j += 64) {
       float v = sr[j] * sc;
-      if (brow && j > 0) v += bias_w * brow[j - 1];
+      if (brow && j > 0) v += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
       const float p = expf(v - mx) * inv;
       orow[j] = accumulate ? orow[j] + p : p;
     }
@@ -298,31 +302,70 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   float mx2 = -INFINITY;
   for (int j = lane; j < N; j += 64) {
     float p = expf(sr[j] * sc - mx) * inv;
-    if (brow && j > 0) p += bias_w * brow[j - 1];
+    if (brow && j > 0) p += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     mx2 = fmaxf(mx2, p);
   }
   mx2 = wave_max(mx2);
   float sum2 = 0.f;
   for (int j = lane; j < N; j += 64) {
     float p = expf(sr[j] * sc - mx) * inv;
-    if (brow && j > 0) p += bias_w * brow[j - 1];
+    if (brow && j > 0) p += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     sum2 += expf(p - mx2);
   }
   sum2 = wave_sum(sum2);
   const float inv2 = 1.0f / sum2;
   for (int j = lane; j < N; j += 64) {
     float p = expf(sr[j] * sc - mx) * inv;
-    if (brow && j > 0) p += bias_w * brow[j - 1];
+    if (brow && j > 0) p += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     const float q = expf(p - mx2) * inv2;
     orow[j] = accumulate ? orow[j] + q : q;
   }
 }
 
 int softmax_rows(const float* scores, int64_t ld, int64_t rows, int N, int H, const float* scale_per_image, float scale,
-                 const float* bias, float bias_w, int mode, int accumulate, float* out, float* lse, hipStream_t s) {
+                 const float* bias, float bias_w, int64_t bias_bstride, const float* bias_rn, const float* bias_cn, int mode,
+                 int accumulate, float* out, float* lse, hipStream_t s) {
   if (rows == 0) return SG_OK;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, scores, ld, rows, N, H, scale_per_image,
-                     scale, bias, bias_w, mode, accumulate, out, lse);
+                     scale, bias, bias_w, bias_bstride, bias_rn, bias_cn, mode, accumulate, out, lse);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// ---- Gaussian neighbourhood bias of NACLIP / NOnly / GAV (reference open_clip/transformer.py:797-820,909-917) ------------------
+// omega[(y,x),(y',x')] = exp(-((y-y')^2 + (x-x')^2) / (2 std^2)) over the patch grid (the CLS row / column is zero and not stored)
+__global__ void gaussian_bias_kernel(int gh, int gw, float inv2s2, float* __restrict__ omega) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = gh * gw;
+  if (i >= (int64_t)n * n) return;
+  const int a = (int)(i / n), b = (int)(i % n);
+  const float dy = (float)(a / gw - b / gw), dx = (float)(a % gw - b % gw);
+  omega[i] = expf(-(dy * dy + dx * dx) * inv2s2);
+}
+int gaussian_bias(int gh, int gw, float std, float* omega, hipStream_t s) {
+  const int64_t total = (int64_t)gh * gw * gh * gw;
+  hipLaunchKernelGGL(gaussian_bias_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, gh, gw, 1.0f / (2.0f * std * std), omega);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+// out[b,h,t] = || x[b,t,h,:] ||   (x: one of the q/k/v slices of the packed qkv)
+template <typename T>
+__global__ __launch_bounds__(256) void head_norms_kernel(const T* __restrict__ x, int64_t sb, int64_t st, int N, int H, int dh, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b, t, h)
+  const int b = blockIdx.y;
+  if (row >= (int64_t)N * H) return;
+  const int t = (int)(row / H), hd = (int)(row % H);
+  const T* p = x + (int64_t)b * sb + (int64_t)t * st + hd * dh;
+  float ss = 0.f;
+  for (int i = lane; i < dh; i += 64) { const float v = to_f32<T>(p[i]); ss += v * v; }
+  ss = wave_sum(ss);
+  if (lane == 0) out[((int64_t)b * H + hd) * N + t] = sqrtf(ss);
+}
+int head_norms(const void* x, int is_bf16, int64_t sb, int64_t st, int B, int N, int H, int dh, float* out, hipStream_t s) {
+  dim3 grid((unsigned)cdiv((int64_t)N * H, 4), (unsigned)B);
+  if (is_bf16) hipLaunchKernelGGL(head_norms_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, sb, st, N, H, dh, out);
+  else hipLaunchKernelGGL(head_norms_kernel<float>, grid, dim3(256), 0, s, (const float*)x, sb, st, N, H, dh, out);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

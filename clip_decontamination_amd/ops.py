@@ -90,9 +90,7 @@ def attention(qkv, heads: int, variant: str = "vanilla", sim=None, sim_weight: f
     a_cls = torch.empty(B, N, dtype=torch.float32, device=qkv.device) if want_stats else None
     a_diag = torch.empty(B, N, dtype=torch.float32, device=qkv.device) if want_stats else None
     pid = precision_id(precision)
-    need = 2 * B * heads * N * 4 + 1024
-    need += (B * N * 4 * D * 2 + 1024) if pid == PREC_BF16 else (2 * B * heads * N * N * 4 + 1024)
-    buf = scratch(need, qkv.device)
+    buf = scratch(lib.sg_op_attention_scratch_bytes(B, N, D, heads, pid), qkv.device)
     sp, sn = _aligned(buf)
     sim = None if sim is None else _f32(sim)
     check(lib.sg_op_attention(ptr(qkv), B, N, D, heads, MODEL_TYPES[variant], ptr(sim), float(sim_weight), ptr(ctx), ptr(a_cls),

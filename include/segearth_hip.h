@@ -188,6 +188,7 @@ int sg_op_layernorm(const float* x, const float* gamma, const float* beta, float
 /* multi-term attention over packed qkv [B,N,3D] (rows q|k|v, nn.MultiheadAttention order);
  * variant = enum sg_model_type (SG_VANILLA = ordinary softmax(q k^T) v). bias: [B,n,n] or NULL.
  * Optional outputs: attn_cls/attn_diag [B,N] head-averaged probabilities (vanilla only). */
+size_t sg_op_attention_scratch_bytes(int B, int N, int D, int H, int precision);
 int sg_op_attention(const float* qkv, int B, int N, int D, int H, int variant, const float* sim, float sim_weight,
                     float* ctx, float* attn_cls, float* attn_diag, int precision, void* scratch, size_t scratch_bytes,
                     sg_stream s);

@@ -94,6 +94,16 @@ def attention_reference(qkv, H, variant, sim=None, w=1.0):
         a = torch.softmax(bias(0.5 * (ss(q) + ss(k))), -1)
     elif variant == "Experimental":
         a = torch.softmax(bias(torch.softmax(ss(k) + ss(q), -1)), -1)
+    elif variant in ("NACLIP", "NOnly", "GAV"):
+        from oracle.vit import gaussian_bias
+        g = int(round((N - 1) ** 0.5))
+        omega = gaussian_bias(g, g)[None, None]
+        if variant == "NACLIP":
+            sco = ss(k)
+        else:
+            omega = omega * scale * (q.norm(dim=-1).unsqueeze(-1) * k.norm(dim=-1).unsqueeze(-2))
+            sco = torch.zeros(B, H, N, N) if variant == "NOnly" else (q @ k.transpose(-1, -2)) * scale
+        a = torch.softmax(sco + omega, -1)
     ctx = (a @ v).permute(0, 2, 1, 3).reshape(B, N, D)
     return ctx, a
 
@@ -113,6 +123,18 @@ def test_attention(ops, B, N, D, H, variant, prec, tol):
     ref, _ = attention_reference(qkv, H, variant, sim, 0.8)
     out = ops.attention(qkv.to(DEV), H, variant, None if sim is None else sim.to(DEV), 0.8, precision=prec)
     assert rel_err(out, ref) < tol, rel_err(out, ref)
+
+
+@pytest.mark.parametrize("variant", ["NACLIP", "NOnly", "GAV"])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2)])
+def test_attention_gaussian_window(ops, variant, prec, tol):
+    """NACLIP / NOnly / GAV (reference open_clip/transformer.py:909-932): Gaussian neighbourhood bias, square grids."""
+    for (B, g, D, H) in ((2, 6, 64, 2), (1, 14, 128, 2), (1, 37, 128, 2)):
+        N = g * g + 1
+        qkv = rnd(B, N, 3 * D, seed=g)
+        ref, _ = attention_reference(qkv, H, variant)
+        out = ops.attention(qkv.to(DEV), H, variant, precision=prec)
+        assert rel_err(out, ref) < tol, (variant, g, rel_err(out, ref))
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16", 3e-2)])
