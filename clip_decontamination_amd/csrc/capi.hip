@@ -243,6 +243,7 @@ struct Plan {
   float *lse, *lse1, *attn_cls, *attn_diag, *out_last, *y; int32_t *idx_out, *idx_sa; void* refine_scratch;
   float *scores, *probs;
   float *omega, *qnorm, *knorm;
+  float *attn_avg, *sa_tmp, *sa_qk32, *sa_scores, *sa_probs;   // self-attention enhancement, mode='attention'
   // GEM
   float* x_gem; void* gnorm[3]; void* gatt[3]; float* inv_temp; float* gem_out; void* ctx2;
 };
@@ -277,6 +278,13 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.refine_scratch = b.take(refine_scratch_bytes(B, d.width, kmax > 0 ? kmax : 1));
   p.scores = p.probs = nullptr;
   if (!c->bf16) { p.scores = b.get<float>((size_t)B * d.heads * N * N); p.probs = b.get<float>((size_t)B * d.heads * N * N); }
+  p.attn_avg = p.sa_tmp = p.sa_qk32 = p.sa_scores = p.sa_probs = nullptr;
+  if (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1) {
+    p.attn_avg = b.get<float>((size_t)B * N * N); p.sa_tmp = b.get<float>(R * d.width);
+    if (c->bf16) {                                        // one image at a time: f32 copies of q|k, scores and probabilities of all heads
+      p.sa_qk32 = b.get<float>((size_t)N * 2 * d.width); p.sa_scores = b.get<float>((size_t)d.heads * N * N); p.sa_probs = b.get<float>((size_t)d.heads * N * N);
+    }
+  }
   p.omega = p.qnorm = p.knorm = nullptr;
   if (o->model_type == SG_NACLIP || o->model_type == SG_NONLY || o->model_type == SG_GAV) {
     p.omega = b.get<float>((size_t)n * n); p.qnorm = b.get<float>((size_t)B * d.heads * N); p.knorm = b.get<float>((size_t)B * d.heads * N);
@@ -482,7 +490,8 @@ static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
 }
 
 // One ordinary residual block (reference open_clip/transformer.py:234-254), x updated in place.
-static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int B, int N, bool stats, hipStream_t s) {
+static int averaged_attention(sg_context* c, const Plan& p, int B, int N, hipStream_t s);
+static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int B, int N, bool stats, hipStream_t s, bool want_avg = false) {
   const sg_vit_desc& d = c->d;
   const int D = d.width, H = d.heads;
   const int64_t R = (int64_t)B * N;
@@ -493,11 +502,40 @@ static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
   if (stats)
     SG_TRY(attention_stats(p.qkv, c->bf16, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), p.attn_cls,
                            p.attn_diag, s));
+  if (want_avg) SG_TRY(averaged_attention(c, p, B, N, s));
   SG_TRY(linear(c->bf16, p.ctx, D, L.w_out, L.b_out, x, x, D, true, (int)R, D, D, ACT_NONE, s));
   return mlp_block(c, L, x, p, R, s);
 }
 
 static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan& p, int B, int N, hipStream_t s);
+
+__global__ void unpack_qk_kernel(const bf16_t* __restrict__ qkv, int N, int D, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * 2 * D) return;
+  const int t = (int)(i / (2 * D)), c = (int)(i % (2 * D));
+  out[i] = bf2f(qkv[(int64_t)t * 3 * D + c]);
+}
+// head-averaged attention matrix [B,N,N] of the block whose packed qkv is in p.qkv (the tensor the reference gets from
+// nn.MultiheadAttention(need_weights=True), transformer.py:609-610).  Only the optional mode='attention' enhancer needs it.
+static int averaged_attention(sg_context* c, const Plan& p, int B, int N, hipStream_t s) {
+  const sg_vit_desc& d = c->d;
+  const int D = d.width, H = d.heads, dh = D / H;
+  const float scale = 1.0f / sqrtf((float)dh);
+  if (!c->bf16) return head_mean(p.probs, B, H, N, p.attn_avg, s);        // parity mode: the probabilities are materialised already
+  const int64_t NN = (int64_t)N * N;
+  for (int b = 0; b < B; ++b) {
+    const bf16_t* qkv = (const bf16_t*)p.qkv + (int64_t)b * N * 3 * D;
+    hipLaunchKernelGGL(unpack_qk_kernel, dim3((unsigned)cdiv((int64_t)N * 2 * D, 256)), dim3(256), 0, s, qkv, N, D, p.sa_qk32);
+    SG_LAUNCH_CHECK();
+    GemmF32Args g{};
+    g.A = p.sa_qk32; g.lda = 2 * D; g.sAi = dh; g.B = p.sa_qk32 + D; g.sbk = 1; g.sbn = 2 * D; g.sBi = dh;
+    g.C = p.sa_scores; g.ldc = N; g.sCi = NN; g.M = N; g.N = N; g.K = dh; g.batch = H; g.inner = H; g.act = 0; g.alpha = 1.f;
+    SG_TRY(gemm_f32(g, s));
+    SG_TRY(softmax_rows(p.sa_scores, N, (int64_t)H * N, N, H, nullptr, scale, nullptr, 0.f, 0, nullptr, nullptr, 0, 0, p.sa_probs, nullptr, s));
+    SG_TRY(head_mean(p.sa_probs, 1, H, N, p.attn_avg + (int64_t)b * NN, s));
+  }
+  return SG_OK;
+}
 
 extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const sg_forward_opts* o, float* out_cls, float* out_tokens,
                               void* workspace, size_t workspace_bytes, sg_stream st) {
@@ -514,8 +552,6 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
   SG_REQUIRE(R * (int64_t)(d.mlp_width > 3 * D ? d.mlp_width : 3 * D) < (1ll << 40), "sg_vit_forward: batch too large");
   if (o->outlier_enabled || o->selfattn_enabled) SG_REQUIRE(gh == gw, "sg_vit_forward: refiners need a square patch grid (reference transformer.py:583)");
   if (o->outlier_enabled) SG_REQUIRE(o->outlier_top_k >= 1, "sg_vit_forward: outlier_top_k must be >= 1");
-  if (o->selfattn_enabled && o->outlier_enabled && o->selfattn_mode != 0)
-    return fail(SG_ERR_INVALID, "sg_vit_forward: self-attention enhancement mode='attention' is not built (SURVEY.md §8f rank 3)");
   Plan p;
   const size_t need = plan(c, B, gh, gw, o, workspace, false, p);
   if (need > workspace_bytes) return fail(SG_ERR_STATE, "sg_vit_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
@@ -541,7 +577,8 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     for (int i = 0; i < L - 1; ++i) {
       if (i == mid && o->similarity_enabled)                          // normalised mid-layer patches (similarity_enhancement.py:49)
         SG_TRY(l2norm_rows(p.x + D, 0, (int64_t)N * D, D, n, p.xhat, c->bf16, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));
-      SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, want_stats && i == L - 2, s));
+      SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, want_stats && i == L - 2, s,
+                       want_stats && i == L - 2 && o->selfattn_enabled && o->selfattn_mode == 1));
     }
     if (o->similarity_enabled)
       SG_TRY(similarity_from_xhat(c->bf16, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s));
@@ -557,7 +594,9 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     SG_TRY(linear(c->bf16, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
     if (!o->ignore_residual) SG_TRY(mlp_block(c, LL, p.out_last, p, R, s));
     // ---- refinements on the last-block output (transformer.py:698-742) ----
-    if (o->outlier_enabled && o->selfattn_enabled) {
+    if (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1) {
+      SG_TRY(attn_mode_enhance(p.out_last, (int64_t)N * D, D, p.attn_avg, B, N, D, o->selfattn_strength, o->selfattn_threshold, p.sa_tmp, s));
+    } else if (o->outlier_enabled && o->selfattn_enabled) {
       const int k = o->selfattn_top_k < n ? o->selfattn_top_k : n;
       SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 1, p.idx_sa, s));
       SG_TRY(neighbour_refine(p.out_last, (int64_t)N * D, D, p.idx_sa, B, gh, gw, D, k, 0, 0.f, p.refine_scratch, s));

@@ -175,8 +175,46 @@ int neighbour_refine(float* tokens, int64_t sb, int64_t st, const int32_t* idx, 
   return SG_OK;
 }
 
-int attn_mode_enhance(float*, int64_t, int64_t, const float*, const float*, int, int, int, float, float, void*, hipStream_t) {
-  return fail(SG_ERR_INVALID, "self-attention enhancement mode='attention' is not built yet (SURVEY.md §8f rank 3)");
+// ---- self-attention enhancement, mode='attention' (reference self_attention_enhancement.py:152-245) ----------------------------
+// A = head-averaged attention of block L-2 [B,N,N].  boost the diagonal of the patch rows by clamp(thr - A[i,i], 0) * strength,
+// L1-renormalise every row (sum + 1e-8), drop the CLS column (the reference feeds a zero CLS feature), then tokens' = A' . tokens.
+__global__ __launch_bounds__(256) void head_mean_kernel(const float* __restrict__ probs, int H, int64_t NN, float* __restrict__ A) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= NN) return;
+  float acc = 0.f;
+  for (int h = 0; h < H; ++h) acc += probs[((int64_t)b * H + h) * NN + i];
+  A[(int64_t)b * NN + i] = acc / (float)H;
+}
+__global__ __launch_bounds__(256) void attn_boost_kernel(float* __restrict__ A, int N, float strength, float thr) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (i >= N) return;
+  float* r = A + ((int64_t)b * N + i) * N;
+  const float boost = i >= 1 ? fmaxf(thr - r[i], 0.f) * strength : 0.f;
+  float sum = 0.f;
+  for (int j = lane; j < N; j += 64) sum += r[j] + (j == i ? boost : 0.f);
+  const float inv = 1.0f / (wave_sum(sum) + 1e-8f);
+  for (int j = lane; j < N; j += 64) r[j] = j == 0 ? 0.f : (r[j] + (j == i ? boost : 0.f)) * inv;
+}
+int head_mean(const float* probs, int B, int H, int N, float* A, hipStream_t s) {
+  const int64_t NN = (int64_t)N * N;
+  hipLaunchKernelGGL(head_mean_kernel, dim3((unsigned)cdiv(NN, 256), (unsigned)B), dim3(256), 0, s, probs, H, NN, A);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+// tokens [B,N,D] f32 (sb, st strides); A [B,N,N] (destroyed); tmp [B,N,D] f32
+int attn_mode_enhance(float* tokens, int64_t sb, int64_t st, float* A, int B, int N, int D, float strength, float threshold, float* tmp,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(attn_boost_kernel, dim3((unsigned)cdiv(N, 4), (unsigned)B), dim3(256), 0, s, A, N, strength, threshold);
+  SG_LAUNCH_CHECK();
+  GemmF32Args g{};
+  g.A = A; g.lda = N; g.sAo = (int64_t)N * N; g.B = tokens; g.sbk = st; g.sbn = 1; g.sBo = sb;
+  g.C = tmp; g.ldc = D; g.sCo = (int64_t)N * D; g.M = N; g.N = D; g.K = N; g.batch = B; g.inner = 1; g.act = 0; g.alpha = 1.f;
+  SG_TRY(gemm_f32(g, s));
+  // patch rows only (the CLS feature is passed through unchanged, transformer.py:703,717)
+  SG_HIP(hipMemcpy2DAsync(tokens + st, (size_t)sb * 4, tmp + D, (size_t)N * D * 4, (size_t)(N - 1) * D * 4, B, hipMemcpyDeviceToDevice, s));
+  return SG_OK;
 }
 
 // ---- cross-tile boundary fusion (reference cross_tile_fusion.py:24-320; unwired there) -----------------------------

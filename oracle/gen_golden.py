@@ -158,6 +158,7 @@ def gen_tiny():
                     "sim": (sim_cfg, None, None), "out": (None, out_cfg, None),
                     "sim_out": (sim_cfg, out_cfg, None), "all": (sim_cfg, out_cfg, sa_cfg),
                     "sa_only": (None, None, sa_cfg),
+                    "sa_attn": (sim_cfg, out_cfg, dict(enhancement_strength=0.3, min_self_attn_threshold=0.15, mode="attention", top_k=4)),
                     "sim2": (dict(similarity_weight=0.5, temperature=2.0, add_self_similarity=False), None, None),
                 }
                 for tag, (sc, oc, ac) in combos.items():

@@ -89,6 +89,7 @@ def test_tiny_residual_native_gelu_f32(golden, tiny_f32):
 COMBOS = {"sim": (SIM, None, None), "out": (None, dict(top_k=5), None), "sim_out": (SIM, dict(top_k=5), None),
           "all": (SIM, dict(top_k=5), dict(enhancement_strength=0.1, min_self_attn_threshold=0.15, mode="feature", top_k=4)),
           "sa_only": (None, None, dict(enhancement_strength=0.1, min_self_attn_threshold=0.15, mode="feature", top_k=4)),
+          "sa_attn": (SIM, dict(top_k=5), dict(enhancement_strength=0.3, min_self_attn_threshold=0.15, mode="attention", top_k=4)),
           "sim2": (dict(similarity_weight=0.5, temperature=2.0, add_self_similarity=False), None, None)}
 
 
@@ -196,3 +197,15 @@ def test_windowed_tiles_equal_cropped_tiles():
         pad = OS.compute_padsize(36, 36, cfg.patch)
         ci, ti = net.encode_image(F.pad(tile, pad), "SegEarth", True, output_cls_token=True)
         assert maxdiff(t[i], ti[0]) < 1e-5 and maxdiff(c[i], ci[0]) < 1e-5
+
+
+@pytest.mark.parametrize("mt", ["SegEarth", "Experimental"])
+def test_tiny_selfattn_attention_mode_bf16(golden, tiny_bf16, mt):
+    """mode='attention' in throughput mode: the head-averaged attention is rebuilt per image in f32 from the bf16 q, k."""
+    cfg, net = tiny_bf16
+    sc, oc, ac = COMBOS["sa_attn"]
+    install(net, sc, oc, ac)
+    g = golden("vit_tiny-8")
+    cls, tok = net.encode_image(torch.from_numpy(g["img"]).to(DEV), mt, True, output_cls_token=True, apply_similarity_enhancement=True)
+    ref = torch.from_numpy(g[f"sa_attn.{mt}.tokens"])
+    assert maxdiff(tok, ref) < 0.08 * ref.abs().max().item()

@@ -55,6 +55,7 @@ OUT = dict(top_k=5)
 SA = dict(enhancement_strength=0.1, min_self_attn_threshold=0.15, mode="feature", top_k=4)
 COMBOS = {"sim": (SIM, None, None), "out": (None, OUT, None), "sim_out": (SIM, OUT, None), "all": (SIM, OUT, SA),
           "sa_only": (None, None, SA),
+          "sa_attn": (SIM, OUT, dict(enhancement_strength=0.3, min_self_attn_threshold=0.15, mode="attention", top_k=4)),
           "sim2": (dict(similarity_weight=0.5, temperature=2.0, add_self_similarity=False), None, None)}
 
 
