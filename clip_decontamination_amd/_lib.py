@@ -69,6 +69,11 @@ SIGNATURES = {
     "sg_op_attention_scratch_bytes": (Z, [I, I, I, I, I]),
     "sg_op_attention": (I, [P, I, I, I, I, I, P, F, P, P, P, I, P, Z, P]),
     "sg_adaptive_conv": (I, [P, P, I, I, I, I, I, P, P]),
+    "sg_text_create": (I, [C.POINTER(P), I, I, I, I, I, I, I, I, I]),
+    "sg_text_destroy": (None, [P]),
+    "sg_text_set_tensor": (I, [P, C.c_char_p, P, L, P]),
+    "sg_text_workspace_bytes": (Z, [P, I]),
+    "sg_text_encode": (I, [P, P, I, P, P, Z, P]),
     "sg_jbu_create": (I, [C.POINTER(P), I, I, I]),
     "sg_jbu_destroy": (None, [P]),
     "sg_jbu_set_tensor": (I, [P, C.c_char_p, P, L, P]),

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
           const float bv = a.bias ? bnext[i] * a.bias_w : 0.f;
           float v = sacc[i >> 4][i & 15] * c2;
           if (a.resoftmax) v = (__builtin_amdgcn_exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
-          sc[i] = key < a.N ? v : -INFINITY;
+          sc[i] = (key < a.N && !(a.causal && key > q_glob)) ? v : -INFINITY;   // causal: text tower (build_causal_mask)
         }
         if (has_next) fetch_bias(k0 + KT);                 // lands under this tile's softmax / PV and the next tile's QK^T
         mloc = sc[0];
@@ -291,7 +291,7 @@ template <int DH, int TS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<DH>;
   const size_t lds = (size_t)2 * (TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
-  const bool generic = a.bias != nullptr || a.resoftmax != 0;
+  const bool generic = a.bias != nullptr || a.resoftmax != 0 || a.causal != 0;
   const bool multi = !a.sum_scores && a.n_terms > 1;
   auto kern = generic ? (multi ? attn_kernel<DH, TS, true, true> : attn_kernel<DH, TS, true, false>)
                       : (multi ? attn_kernel<DH, TS, false, true> : attn_kernel<DH, TS, false, false>);

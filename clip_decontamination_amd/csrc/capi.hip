@@ -107,7 +107,7 @@ struct AttnBuffers { float* scores; float* probs; float* lse; float* lse1; float
 struct AttnSpec {
   const void* q[3]; const void* k[3]; int64_t sb, st;
   const void* v; int64_t v_sb, v_st;
-  int n_terms, sum_scores, resoftmax;
+  int n_terms, sum_scores, resoftmax, causal;
   float scale; const float* scale_per_image;
   const float* bias; float bias_w; int64_t bias_bstride; const float* bias_rn; const float* bias_cn;
   float out_scale;
@@ -120,7 +120,7 @@ static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int 
     AttnArgs a{};
     for (int t = 0; t < sp.n_terms; ++t) { a.q[t] = (const bf16_t*)sp.q[t]; a.k[t] = (const bf16_t*)sp.k[t]; }
     a.v = (const bf16_t*)sp.v; a.sb = sp.sb; a.st = sp.st; a.v_sb = sp.v_sb; a.v_st = sp.v_st;
-    a.n_terms = sp.n_terms; a.sum_scores = sp.sum_scores;
+    a.n_terms = sp.n_terms; a.sum_scores = sp.sum_scores; a.causal = sp.causal;
     a.B = B; a.N = N; a.H = H; a.dh = dh; a.scale = sp.scale; a.scale_per_image = sp.scale_per_image;
     a.out_scale = sp.out_scale; a.ctx_sb = sp.ctx_sb; a.ctx_st = sp.ctx_st;
     if (sp.resoftmax) {
@@ -150,7 +150,7 @@ static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int 
     for (int t = 0; t < sp.n_terms; ++t) {
       SG_TRY(scores_of(t, false));
       SG_TRY(softmax_rows(buf.scores, N, rows, N, H, sp.scale_per_image, sp.scale, sp.bias, sp.bias_w, sp.bias_bstride, sp.bias_rn, sp.bias_cn, 0, t > 0, buf.probs,
-                          (sp.want_lse && t == 0) ? buf.lse : nullptr, s));
+                          (sp.want_lse && t == 0) ? buf.lse : nullptr, s, sp.causal));
     }
   }
   GemmF32Args g{};
@@ -163,7 +163,7 @@ static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int 
 
 // Attention over packed qkv [B,N,3D] (compute dtype) -> ctx [B,N,D] (compute dtype).
 static int run_attention(bool bf16, const void* qkv, int B, int N, int D, int H, int model_type, const float* sim, float sim_w,
-                         const float* scale_per_image, void* ctx, bool want_lse, const AttnBuffers& buf, hipStream_t s) {
+                         const float* scale_per_image, void* ctx, bool want_lse, const AttnBuffers& buf, hipStream_t s, bool causal = false) {
   const int dh = D / H;
   Variant v;
   if (!variant_of(model_type, v)) return fail(SG_ERR_INVALID, "attention variant %d is not built (NACLIP / NOnly / GAV: SURVEY.md §8f rank 3)", model_type);
@@ -172,7 +172,7 @@ static int run_attention(bool bf16, const void* qkv, int B, int N, int D, int H,
   for (int t = 0; t < v.n_terms; ++t) { sp.q[t] = (const char*)qkv + (size_t)v.qsel[t] * D * e; sp.k[t] = (const char*)qkv + (size_t)v.ksel[t] * D * e; }
   sp.v = (const char*)qkv + (size_t)2 * D * e;
   sp.st = sp.v_st = 3 * (int64_t)D; sp.sb = sp.v_sb = (int64_t)N * 3 * D;
-  sp.n_terms = v.n_terms; sp.sum_scores = v.sum_scores; sp.resoftmax = v.resoftmax;
+  sp.n_terms = v.n_terms; sp.sum_scores = v.sum_scores; sp.resoftmax = v.resoftmax; sp.causal = causal ? 1 : 0;
   sp.scale = v.scale_mul / sqrtf((float)dh); sp.scale_per_image = scale_per_image;
   sp.bias = sim; sp.bias_w = sim_w; sp.bias_bstride = (int64_t)(N - 1) * (N - 1); sp.out_scale = 1.f;
   if (v.gauss) {
@@ -491,14 +491,15 @@ static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
 
 // One ordinary residual block (reference open_clip/transformer.py:234-254), x updated in place.
 static int averaged_attention(sg_context* c, const Plan& p, int B, int N, hipStream_t s);
-static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int B, int N, bool stats, hipStream_t s, bool want_avg = false) {
+static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int B, int N, bool stats, hipStream_t s, bool want_avg = false,
+                     bool causal = false) {
   const sg_vit_desc& d = c->d;
   const int D = d.width, H = d.heads;
   const int64_t R = (int64_t)B * N;
   AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1, p.omega, p.qnorm, p.knorm};
   SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
   SG_TRY(linear(c->bf16, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
-  SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s));
+  SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s, causal));
   if (stats)
     SG_TRY(attention_stats(p.qkv, c->bf16, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), p.attn_cls,
                            p.attn_diag, s));
@@ -662,6 +663,180 @@ static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan&
     SG_TRY(mlp_block(c, LW, p.x, p, R, s));
   }
   return SG_OK;
+}
+
+
+// ---- CLIP text tower (reference open_clip/model.py:288-306 encode_text; init-time producer of query_features) --------------------
+// Same residual blocks as the vision tower (nn.MultiheadAttention + MLP) with the causal mask of build_causal_mask, token +
+// positional embedding in front, ln_final + EOT pooling (argmax of the token ids) + text_projection behind.
+struct sg_text {
+  sg_context core;                 // reuses the block machinery: width / heads / mlp / layers / precision live in core.d
+  int context_length, vocab_size, embed_dim;
+  float *tok_emb, *pos_emb, *lnf_g, *lnf_b;
+  void* w_projT;                   // [E, W]
+  std::vector<uint8_t> have_text;
+};
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos, int S, int ctx, int W, int vocab, float* __restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)S * ctx * W) return;
+  const int c = (int)(i % W);
+  const int64_t row = i / W;
+  const int t = (int)(row % ctx);
+  int id = tokens[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  x[i] = tok_emb[(int64_t)id * W + c] + pos[(int64_t)t * W + c];
+}
+// pooled[s,:] = x[s, argmax_t tokens[s,t], :]   (text_global_pool 'argmax': the EOT token has the highest id; first maximum wins)
+__global__ __launch_bounds__(256) void text_pool_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ x, int ctx, int W,
+                                                        float* __restrict__ pooled) {
+  __shared__ int s_arg;
+  const int sidx = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int best = tokens[(int64_t)sidx * ctx], arg = 0;
+    for (int t = 1; t < ctx; ++t) { const int v = tokens[(int64_t)sidx * ctx + t]; if (v > best) { best = v; arg = t; } }
+    s_arg = arg;
+  }
+  __syncthreads();
+  const float* src = x + ((int64_t)sidx * ctx + s_arg) * W;
+  for (int c = threadIdx.x; c < W; c += 256) pooled[(int64_t)sidx * W + c] = src[c];
+}
+
+extern "C" int sg_text_create(sg_text** out, int device, int width, int layers, int heads, int context_length, int vocab_size, int embed_dim,
+                              int quick_gelu, int precision) {
+  SG_REQUIRE(out && width > 0 && layers > 0 && heads > 0 && width % heads == 0 && context_length > 0 && vocab_size > 0 && embed_dim > 0,
+             "sg_text_create: bad arguments");
+  SG_REQUIRE(precision == SG_PREC_F32 || precision == SG_PREC_BF16, "sg_text_create: bad precision");
+  SG_REQUIRE(width % 4 == 0 && embed_dim % 4 == 0, "sg_text_create: width / embed_dim must be multiples of 4");
+  if (precision == SG_PREC_BF16) {
+    const int dh = width / heads;
+    SG_REQUIRE(width % 64 == 0 && (dh == 32 || dh == 64 || dh == 80 || dh == 128), "sg_text_create: bf16 mode needs width %% 64 == 0 and head_dim 32/64/80/128");
+  }
+  SG_HIP(hipSetDevice(device));
+  sg_text* t = new sg_text();
+  sg_context& c = t->core;
+  c.d = sg_vit_desc{width, layers, heads, 1, embed_dim, 1, 4 * width, quick_gelu, precision};
+  c.device = device; c.bf16 = precision == SG_PREC_BF16; c.esz = c.bf16 ? 2 : 4; c.Kpatch = c.Kpad = 0; c.finalized = false;
+  t->context_length = context_length; t->vocab_size = vocab_size; t->embed_dim = embed_dim;
+  auto lay = [&](Bump& bb) {
+    const size_t e = c.esz; const int D = width, M = 4 * width;
+    t->tok_emb = bb.get<float>((size_t)vocab_size * D); t->pos_emb = bb.get<float>((size_t)context_length * D);
+    t->lnf_g = bb.get<float>(D); t->lnf_b = bb.get<float>(D); t->w_projT = bb.take((size_t)embed_dim * D * e);
+    c.layers.resize(layers);
+    for (auto& L : c.layers) {
+      L.w_qkv = bb.take((size_t)3 * D * D * e); L.w_out = bb.take((size_t)D * D * e);
+      L.w_fc = bb.take((size_t)M * D * e); L.w_proj = bb.take((size_t)D * M * e);
+      L.b_qkv = bb.get<float>(3 * D); L.b_out = bb.get<float>(D); L.b_fc = bb.get<float>(M); L.b_proj = bb.get<float>(D);
+      L.ln1_g = bb.get<float>(D); L.ln1_b = bb.get<float>(D); L.ln2_g = bb.get<float>(D); L.ln2_b = bb.get<float>(D);
+    }
+  };
+  Bump dry(nullptr, 0, true); lay(dry);
+  c.arena_bytes = align_up(dry.off, 256);
+  hipError_t e = hipMalloc(&c.arena, c.arena_bytes);
+  if (e != hipSuccess) { delete t; return fail(SG_ERR_HIP, "sg_text_create: hipMalloc(%zu) -> %s", c.arena_bytes, hipGetErrorString(e)); }
+  Bump real(c.arena, c.arena_bytes, false); lay(real);
+  t->have_text.assign(5 + 12 * layers, 0);
+  *out = t;
+  return SG_OK;
+}
+
+extern "C" void sg_text_destroy(sg_text* t) {
+  if (!t) return;
+  if (t->core.arena) (void)hipFree(t->core.arena);
+  delete t;
+}
+
+extern "C" int sg_text_set_tensor(sg_text* t, const char* name, const float* src, int64_t numel, sg_stream st) {
+  SG_REQUIRE(t && name && src, "sg_text_set_tensor: null argument");
+  hipStream_t s = as_stream(st);
+  sg_context& c = t->core;
+  const int D = c.d.width, M = c.d.mlp_width, E = t->embed_dim;
+  const int to_bf16 = c.bf16 ? 1 : 0;
+  auto copyf = [&](float* dst, int64_t n) -> int {
+    SG_REQUIRE(numel == n, "sg_text_set_tensor(%s): expected %lld elements, got %lld", name, (long long)n, (long long)numel);
+    SG_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return SG_OK;
+  };
+  auto packw = [&](void* dst, int rows, int cols) -> int {
+    SG_REQUIRE(numel == (int64_t)rows * cols, "sg_text_set_tensor(%s): expected %lld elements, got %lld", name, (long long)rows * cols, (long long)numel);
+    return pack_rows(src, rows, cols, cols, dst, cols, to_bf16, s);
+  };
+  int slot = -1, rc = SG_OK;
+  if (!strcmp(name, "token_embedding.weight")) { slot = 0; rc = copyf(t->tok_emb, (int64_t)t->vocab_size * D); }
+  else if (!strcmp(name, "positional_embedding")) { slot = 1; rc = copyf(t->pos_emb, (int64_t)t->context_length * D); }
+  else if (!strcmp(name, "ln_final.weight")) { slot = 2; rc = copyf(t->lnf_g, D); }
+  else if (!strcmp(name, "ln_final.bias")) { slot = 3; rc = copyf(t->lnf_b, D); }
+  else if (!strcmp(name, "text_projection")) {
+    slot = 4;
+    SG_REQUIRE(numel == (int64_t)D * E, "sg_text_set_tensor(text_projection): expected %d x %d", D, E);
+    rc = transpose_pack(src, D, E, t->w_projT, to_bf16, s);
+  } else {
+    int li = -1, consumed = 0, tt;
+    if (sscanf(name, "transformer.resblocks.%d.%n", &li, &consumed) == 1 && consumed > 0 && li >= 0 && li < c.d.layers &&
+        find_layer_tensor(name + consumed, tt)) {
+      LayerW& L = c.layers[li];
+      slot = 5 + li * 12 + tt;
+      switch (tt) {
+        case 0: rc = copyf(L.ln1_g, D); break;
+        case 1: rc = copyf(L.ln1_b, D); break;
+        case 2: rc = packw(L.w_qkv, 3 * D, D); break;
+        case 3: rc = copyf(L.b_qkv, 3 * D); break;
+        case 4: rc = packw(L.w_out, D, D); break;
+        case 5: rc = copyf(L.b_out, D); break;
+        case 6: rc = copyf(L.ln2_g, D); break;
+        case 7: rc = copyf(L.ln2_b, D); break;
+        case 8: rc = packw(L.w_fc, M, D); break;
+        case 9: rc = copyf(L.b_fc, M); break;
+        case 10: rc = packw(L.w_proj, D, M); break;
+        case 11: rc = copyf(L.b_proj, D); break;
+      }
+    }
+  }
+  if (slot < 0) return fail(SG_ERR_INVALID, "sg_text_set_tensor: unknown tensor name '%s'", name);
+  if (rc != SG_OK) return rc;
+  t->have_text[slot] = 1;
+  return SG_OK;
+}
+
+static size_t text_plan(const sg_text* t, int S, void* ws, bool dry, Plan& p, float*& pooled, float*& x) {
+  const sg_context& c = t->core;
+  const int N = t->context_length, D = c.d.width;
+  const int64_t R = (int64_t)S * N;
+  Bump b(ws, 0, dry);
+  x = b.get<float>(R * D);
+  p.xn = b.take(R * D * c.esz); p.qkv = b.take(R * 3 * D * c.esz); p.ctx = b.take(R * D * c.esz); p.hbuf = b.take(R * c.d.mlp_width * c.esz);
+  p.lse = b.get<float>((size_t)S * c.d.heads * N); p.lse1 = b.get<float>((size_t)S * c.d.heads * N);
+  p.attn_cls = p.attn_diag = nullptr; p.omega = p.qnorm = p.knorm = nullptr; p.attn_avg = nullptr;
+  p.scores = p.probs = nullptr;
+  if (!c.bf16) { p.scores = b.get<float>((size_t)S * c.d.heads * N * N); p.probs = b.get<float>((size_t)S * c.d.heads * N * N); }
+  pooled = b.get<float>((size_t)S * D);
+  return align_up(b.off, 256);
+}
+
+extern "C" size_t sg_text_workspace_bytes(const sg_text* t, int n_seq) {
+  if (!t || n_seq <= 0) return 0;
+  Plan p{}; float *a, *b;
+  return text_plan(t, n_seq, nullptr, true, p, a, b);
+}
+
+// tokens int32 [S, context_length] (device) -> out [S, E] f32 (un-normalised, as encode_text(normalize=False))
+extern "C" int sg_text_encode(sg_text* t, const int32_t* tokens, int n_seq, float* out, void* workspace, size_t workspace_bytes, sg_stream st) {
+  SG_REQUIRE(t && tokens && out && workspace && n_seq > 0, "sg_text_encode: bad arguments");
+  for (size_t i = 0; i < t->have_text.size(); ++i) if (!t->have_text[i]) return fail(SG_ERR_STATE, "sg_text_encode: text weights incomplete");
+  hipStream_t s = as_stream(st);
+  sg_context& c = t->core;
+  const int N = t->context_length, D = c.d.width, E = t->embed_dim, S = n_seq;
+  const int64_t R = (int64_t)S * N;
+  Plan p{}; float *pooled, *x;
+  const size_t need = text_plan(t, S, workspace, false, p, pooled, x);
+  if (need > workspace_bytes) return fail(SG_ERR_STATE, "sg_text_encode: workspace %zu < required %zu", workspace_bytes, need);
+  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, tokens, t->tok_emb, t->pos_emb, S, N, D, t->vocab_size, x);
+  SG_LAUNCH_CHECK();
+  for (int i = 0; i < c.d.layers; ++i) SG_TRY(std_block(&c, c.layers[i], x, p, S, N, false, s, false, /*causal=*/true));
+  hipLaunchKernelGGL(text_pool_kernel, dim3(S), dim3(256), 0, s, tokens, x, N, D, pooled);
+  SG_LAUNCH_CHECK();
+  SG_TRY(layernorm(pooled, D, t->lnf_g, t->lnf_b, p.xn, D, c.bf16, S, D, 1e-5f, s));
+  return linear(c.bf16, p.xn, D, t->w_projT, nullptr, nullptr, out, E, true, S, E, D, ACT_NONE, s);
 }
 
 // ---- stand-alone ops ------------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ int l2norm_rows(const void* x, int x_bf16, int64_t so, int64_t si, int inner, vo
                 int64_t rows, int D, float eps, hipStream_t s);
 int softmax_rows(const float* scores, int64_t ld, int64_t rows, int N, int H, const float* scale_per_image, float scale,
                  const float* bias, float bias_w, int64_t bias_bstride, const float* bias_rn, const float* bias_cn, int mode,
-                 int accumulate, float* out, float* lse, hipStream_t s);
+                 int accumulate, float* out, float* lse, hipStream_t s, int causal = 0);
 int gaussian_bias(int gh, int gw, float std, float* omega, hipStream_t s);
 int head_norms(const void* x, int is_bf16, int64_t sb, int64_t st, int B, int N, int H, int dh, float* out, hipStream_t s);
 int axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s);
@@ -38,6 +38,7 @@ struct AttnArgs {
   const float* bias; float bias_w;          // [B, N-1, N-1] symmetric, or null; batch stride bias_bstride (0 = shared by all images)
   int64_t bias_bstride;
   const float* bias_rn; const float* bias_cn; // optional [B,H,N] row / column factors of the bias (NOnly / GAV: |q_i|, |k_j|)
+  int causal;                               // keys after the query are masked (CLIP text tower)
   int resoftmax;                            // 'Experimental': softmax(softmax(score) + bias_w*bias); needs lse_in
   const float* lse_in;                      // [B,H,N] log-sum-exp of the first softmax (resoftmax)
   float* lse_out;                           // [B,H,N] or null; when ctx == null only the LSE pass runs

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                                                            const float* __restrict__ scale_per_image, float scale,
                                                            const float* __restrict__ bias, float bias_w, int64_t bias_bstride,
                                                            const float* __restrict__ bias_rn, const float* __restrict__ bias_cn,
-                                                           int mode, int accumulate, float* __restrict__ out, float* __restrict__ lse) {
+                                                           int mode, int accumulate, float* __restrict__ out, float* __restrict__ lse, int causal) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -270,19 +270,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   const float* sr = scores + row * ld;
   float* orow = out + row * ld;
   const int n = N - 1;
+  const int Nk = causal ? i + 1 : N;                      // causal: only keys <= query take part; the rest get probability 0
   const float* brow = (bias && i > 0) ? bias + b * bias_bstride + (int64_t)(i - 1) * n : nullptr;   // bias[b, i-1, :]
   const int hd = (int)((row / N) % H);
   const float* cn = bias_cn ? bias_cn + (b * H + hd) * (int64_t)N : nullptr;
   if (bias_rn) bias_w *= bias_rn[(b * H + hd) * (int64_t)N + i];
   float mx = -INFINITY;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = lane; j < Nk; j += 64) {
     float v = sr[j] * sc;
     if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     mx = fmaxf(mx, v);
   }
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = lane; j < Nk; j += 64) {
     float v = sr[j] * sc;
     if (mode == 0 && brow && j > 0) v += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     sum += expf(v - mx);
@@ -291,30 +292,31 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   if (lse && lane == 0) lse[row] = mx + logf(sum);
   const float inv = 1.0f / sum;
   if (mode == 0) {
-    for (int j = lane; j < N; j += 64) {
+    for (int j = lane; j < Nk; j += 64) {
       float v = sr[j] * sc;
       if (brow && j > 0) v += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
       const float p = expf(v - mx) * inv;
       orow[j] = accumulate ? orow[j] + p : p;
     }
+    if (!accumulate) for (int j = Nk + lane; j < N; j += 64) orow[j] = 0.f;
     return;
   }
   float mx2 = -INFINITY;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = lane; j < Nk; j += 64) {
     float p = expf(sr[j] * sc - mx) * inv;
     if (brow && j > 0) p += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     mx2 = fmaxf(mx2, p);
   }
   mx2 = wave_max(mx2);
   float sum2 = 0.f;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = lane; j < Nk; j += 64) {
     float p = expf(sr[j] * sc - mx) * inv;
     if (brow && j > 0) p += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     sum2 += expf(p - mx2);
   }
   sum2 = wave_sum(sum2);
   const float inv2 = 1.0f / sum2;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = lane; j < Nk; j += 64) {
     float p = expf(sr[j] * sc - mx) * inv;
     if (brow && j > 0) p += bias_w * brow[j - 1] * (cn ? cn[j] : 1.f);
     const float q = expf(p - mx2) * inv2;
@@ -324,10 +326,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 int softmax_rows(const float* scores, int64_t ld, int64_t rows, int N, int H, const float* scale_per_image, float scale,
                  const float* bias, float bias_w, int64_t bias_bstride, const float* bias_rn, const float* bias_cn, int mode,
-                 int accumulate, float* out, float* lse, hipStream_t s) {
+                 int accumulate, float* out, float* lse, hipStream_t s, int causal) {
   if (rows == 0) return SG_OK;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, scores, ld, rows, N, H, scale_per_image,
-                     scale, bias, bias_w, bias_bstride, bias_rn, bias_cn, mode, accumulate, out, lse);
+                     scale, bias, bias_w, bias_bstride, bias_rn, bias_cn, mode, accumulate, out, lse, causal);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from ._lib import ForwardOpts, MODEL_TYPES, TileBatch, VitDesc, check
 from .ops import precision_id, ptr, stream_ptr
-from .weights import VitConfig
+from .weights import TextConfig, VitConfig
 
 
 def compute_padsize(H: int, W: int, patch_size: int) -> Tuple[int, int, int, int]:
@@ -195,11 +195,78 @@ class HipVisionTower:
         return tok
 
 
-class HipCLIP:
-    """The ``net`` of the drop-in segmentors: ``.visual`` + ``.encode_image`` with the reference signature."""
+class HipTextTower:
+    """The text half of ``CLIP`` (open_clip/model.py:288-306): a ``sg_text`` context; ``encode_text(ids)`` runs in HIP.
 
-    def __init__(self, visual: HipVisionTower):
+    Init-time producer of ``query_features`` (segmentor.py:157-174).  Token ids come from the caller's tokenizer (the BPE
+    vocabulary is a downloaded asset, out of scope); everything after the ids is computed here."""
+
+    def __init__(self, cfg: TextConfig, state_dict, precision="f32", device: "torch.device | str | int" = "cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipTextTower needs a GPU: there is no CPU implementation")
+        self.cfg = cfg
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.precision = precision_id(precision)
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.sg_text_create(C.byref(self._ctx), self.device.index or 0, cfg.width, cfg.layers, cfg.heads, cfg.context_length,
+                                          cfg.vocab_size, cfg.embed_dim, int(cfg.quick_gelu), self.precision), "sg_text_create")
+            s = stream_ptr()
+            wanted = ("token_embedding.", "positional_embedding", "transformer.", "ln_final.", "text_projection")
+            for name, value in state_dict.items():
+                if name.startswith("visual.") or not name.startswith(wanted):
+                    continue                                             # full CLIP state dicts carry visual.* and logit_scale too
+                t = torch.as_tensor(value) if not torch.is_tensor(value) else value
+                t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+                check(self.lib.sg_text_set_tensor(self._ctx, name.encode(), ptr(t), t.numel(), s), f"sg_text_set_tensor({name})")
+            torch.cuda.current_stream().synchronize()
+
+    def __del__(self):
+        ctx = getattr(self, "_ctx", None)
+        if ctx is not None and ctx.value:
+            self.lib.sg_text_destroy(ctx)
+            self._ctx = C.c_void_p()
+
+    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """text: int [S, context_length] token ids -> [S, E] f32."""
+        if text.dim() != 2 or text.shape[1] != self.cfg.context_length:
+            raise ValueError(f"token ids must be [S, {self.cfg.context_length}], got {tuple(text.shape)}")
+        ids = text.to(device=self.device, dtype=torch.int32).contiguous()
+        S = ids.shape[0]
+        out = torch.empty(S, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        if S == 0:
+            return out
+        with torch.cuda.device(self.device):
+            need = self.lib.sg_text_workspace_bytes(self._ctx, S)
+            ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            base = ws.data_ptr() + (-ws.data_ptr()) % 256
+            check(self.lib.sg_text_encode(self._ctx, ptr(ids), S, ptr(out), C.c_void_p(base), need, stream_ptr()), "sg_text_encode")
+        return torch.nn.functional.normalize(out, dim=-1) if normalize else out
+
+    def query_features(self, tokenizer, query_words: Sequence[str]) -> torch.Tensor:
+        """segmentor.py:157-174: 80-template prompt ensemble per query word, all words in ONE encode launch."""
+        from .prompts import ensemble_prompts
+        batches = [torch.as_tensor(tokenizer(ensemble_prompts(qw))) for qw in query_words]
+        n = [b.shape[0] for b in batches]
+        f = self.encode_text(torch.cat(batches, 0))
+        f = f / f.norm(dim=-1, keepdim=True)
+        rows = [c.mean(dim=0) for c in f.split(n, dim=0)]
+        q = torch.stack(rows)
+        return q / q.norm(dim=-1, keepdim=True)
+
+
+class HipCLIP:
+    """The ``net`` of the drop-in segmentors: ``.visual`` + ``.encode_image`` (+ ``.encode_text``) with the reference signatures."""
+
+    def __init__(self, visual: HipVisionTower, text: Optional[HipTextTower] = None):
         self.visual = visual
+        self.text = text
+
+    def encode_text(self, text, normalize: bool = False):
+        if self.text is None:
+            raise RuntimeError("this HipCLIP was built without text-tower weights")
+        return self.text.encode_text(text, normalize)
 
     def eval(self):
         return self

@@ -6,10 +6,11 @@ What differs, and why (none of it is on the hot path):
   * weights: every pretrained tag of the reference resolves to a download (segmentor.py:69-128), impossible
     offline.  The drop-in takes ``checkpoint=`` (a local state dict holding ``visual.*`` tensors, loaded with
     ``weights_only=True``) or, with ``synthetic_ok=True``, the deterministic synthetic weights used for parity.
-  * text features: the text tower is init-time input production (not built yet).  Pass
-    ``text_features=`` ([Q,E] tensor / .npy / .pt path) or ``text_encoder=`` (callable: list[str] -> [n,E]
-    tensor, e.g. any CLIP text tower); the 80-template prompt ensemble of segmentor.py:157-174 is applied to
-    the latter here.
+  * text features: ``tokenizer=`` (callable: list[str] -> int ids [n, 77]; the BPE vocabulary is a downloaded
+    asset) together with a ``checkpoint`` that holds the text tower runs the reference's own route
+    (segmentor.py:157-174) on the HIP text tower (``sg_text_encode``).  Alternatives: ``text_features=`` ([Q,E]
+    tensor / .npy / .pt path) or ``text_encoder=`` (callable: list[str] -> [n,E] tensor); the 80-template
+    prompt ensemble is applied here in every case.
 """
 from __future__ import annotations
 
@@ -82,6 +83,18 @@ def _vit_name(clip_type: str, vit_type: str) -> str:
     raise ValueError(f"unsupported vit_type {vit_type!r}")
 
 
+def _load_full_state(path: str):
+    """The whole CLIP state dict (text tower included); loaders that execute nothing from the file."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return {k: torch.from_numpy(z[k]) for k in z.files}
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    return sd["state_dict"] if isinstance(sd, dict) and "state_dict" in sd else sd
+
+
 def _load_state(path: str):
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
@@ -112,7 +125,7 @@ class _HipSegmentorBase(_Base):
     def _setup(self, clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                slide_crop, cls_token_lambda, bg_idx, apply_sim_feat_up, sim_feat_up_cfg, global_debias_factor=0.0,
                checkpoint=None, text_features=None, text_encoder: Optional[Callable] = None, precision="bf16",
-               synthetic_ok=False, tiles_per_launch=32, jbu_checkpoint_ok=True):
+               synthetic_ok=False, tiles_per_launch=32, jbu_checkpoint_ok=True, tokenizer: Optional[Callable] = None):
         if clip_type == "BLIP":
             raise NotImplementedError("clip_type='BLIP' is a different backbone (vendored BLIP) and is out of scope for the HIP path")
         self.clip_type, self.vit_type, self.model_type = clip_type, vit_type, model_type
@@ -161,12 +174,25 @@ class _HipSegmentorBase(_Base):
                     f = f.mean(dim=0)
                     feats.append((f / f.norm()).unsqueeze(0))
             tf = torch.cat(feats, 0)
+        elif tokenizer is not None:
+            # the reference's own route (segmentor.py:157-174): tokenizer -> net.encode_text, here on the HIP text tower
+            from .engine import HipTextTower
+            full = _load_full_state(checkpoint) if checkpoint else None
+            if not full or "token_embedding.weight" not in full:
+                raise RuntimeError("tokenizer= given but the checkpoint holds no text tower (token_embedding.weight ...)")
+            tcfg = Wt.TEXT_CONFIGS[cfg.name] if cfg.name in Wt.TEXT_CONFIGS else None
+            if tcfg is None:
+                raise RuntimeError(f"no text configuration known for {cfg.name}")
+            if tcfg.quick_gelu != quick:
+                tcfg = Wt.TextConfig(**{**tcfg.__dict__, "quick_gelu": quick})
+            self.net.text = HipTextTower(tcfg, full, precision="f32", device=dev)
+            tf = self.net.text.query_features(tokenizer, query_words).cpu()
         elif synthetic_ok:
             warnings.warn("SegEarth drop-in: using SYNTHETIC text features")
             tf = torch.from_numpy(Wt.make_text_features(self.num_queries, E))
         else:
-            raise RuntimeError("no text features: pass text_features=[Q,E] or text_encoder=callable (the text tower is not "
-                               "part of the HIP path yet, SURVEY.md §8f rank 1)")
+            raise RuntimeError("no text features: pass text_features=[Q,E], text_encoder=callable, or tokenizer=callable together "
+                               "with a checkpoint that holds the text tower")
         if tuple(tf.shape) != (self.num_queries, E):
             raise ValueError(f"text features have shape {tuple(tf.shape)}, expected ({self.num_queries}, {E})")
         self.query_features = tf.to(dev)
@@ -267,7 +293,8 @@ class SegmentorEx(_HipSegmentorBase):
                  layer_fusion_lambda=0.5, layer_fusion_threshold=0.7, apply_similarity_enhancement=False,
                  similarity_enhancement_cfg=None, result_dir=None, heatmap_dir=None,
                  # -- drop-in extras (see module docstring) --
-                 checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32):
+                 checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
+                 tokenizer=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
         if model_type == "GEM":
@@ -279,7 +306,7 @@ class SegmentorEx(_HipSegmentorBase):
             raise NotImplementedError("apply_layer_fusion is internally inconsistent in the reference (SURVEY.md R9) and is not built")
         visual = self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                              slide_crop, cls_token_lambda, bg_idx, _to_bool(apply_sim_feat_up), sim_feat_up_cfg, global_debias_factor,
-                             checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch)
+                             checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer)
         self.apply_ctd = False
         self.apply_layer_fusion, self.layer_fusion_lambda, self.layer_fusion_threshold = False, layer_fusion_lambda, layer_fusion_threshold
         self.apply_similarity_enhancement = _to_bool(apply_similarity_enhancement)
@@ -307,13 +334,14 @@ class Segmentor(_HipSegmentorBase):
     def __init__(self, clip_type, vit_type, model_type, name_path, device=torch.device("cuda"), ignore_residual=True, prob_thd=0.0,
                  logit_scale=50, slide_stride=112, slide_crop=224, cls_token_lambda=0, bg_idx=0, apply_sim_feat_up=True,
                  sim_feat_up_cfg=dict(model_name="jbu_one", model_path="your/model/path"),
-                 checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32):
+                 checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
+                 tokenizer=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
         if model_type == "GEM" and cls_token_lambda != 0:
             raise ValueError("GEM returns no CLS token (gem_utils.py:198-199): cls_token_lambda must be 0 (SURVEY.md R5)")
         self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                     slide_crop, cls_token_lambda, bg_idx, apply_sim_feat_up, sim_feat_up_cfg, 0.0,
-                    checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch)
+                    checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer)
         self.output_cls_token = cls_token_lambda != 0
         self.apply_similarity_enhancement = False

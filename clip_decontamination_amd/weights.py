@@ -128,6 +128,70 @@ def make_vit_weights(cfg: VitConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     return w
 
 
+@dataclass(frozen=True)
+class TextConfig:
+    """Text-tower hyper-parameters (reference open_clip/model.py CLIPTextCfg; model_configs/*.json "text_cfg")."""
+    name: str
+    width: int
+    layers: int
+    heads: int
+    embed_dim: int
+    context_length: int = 77
+    vocab_size: int = 49408
+    quick_gelu: bool = True
+
+
+TEXT_CONFIGS: Dict[str, TextConfig] = {
+    "ViT-B-16": TextConfig("ViT-B-16", 512, 12, 8, 512),
+    "ViT-B-32": TextConfig("ViT-B-32", 512, 12, 8, 512),
+    "ViT-L-14": TextConfig("ViT-L-14", 768, 12, 12, 768),
+    "ViT-H-14": TextConfig("ViT-H-14", 1024, 24, 16, 1024, quick_gelu=False),
+    "tiny-text": TextConfig("tiny-text", 64, 3, 2, 32, context_length=12, vocab_size=100),
+    "tiny-8": TextConfig("tiny-8", 64, 3, 2, 32, context_length=12, vocab_size=100),          # text half paired with the tiny-8 ViT
+    "tiny-text-gelu": TextConfig("tiny-text-gelu", 64, 2, 2, 32, context_length=77, vocab_size=100, quick_gelu=False),
+}
+
+
+def make_text_weights(cfg: TextConfig, seed: int = 0) -> Dict[str, np.ndarray]:
+    """fp32 numpy state dict of the text tower, keys as the text part of ``CLIP.state_dict()``."""
+    D, L, E = cfg.width, cfg.layers, cfg.embed_dim
+    M = 4 * D
+    proj_std = (D ** -0.5) * ((2 * L) ** -0.5)
+    w: Dict[str, np.ndarray] = {}
+    w["token_embedding.weight"] = _normal(seed, "t.token_embedding.weight", (cfg.vocab_size, D), 0.3)
+    w["positional_embedding"] = _normal(seed, "t.positional_embedding", (cfg.context_length, D), 0.1)
+    for i in range(L):
+        p = f"transformer.resblocks.{i}."
+        for ln in ("ln_1", "ln_2"):
+            w[p + f"{ln}.weight"] = _normal(seed, "t." + p + f"{ln}.weight", (D,), 0.1, 1.0)
+            w[p + f"{ln}.bias"] = _normal(seed, "t." + p + f"{ln}.bias", (D,), 0.05)
+        w[p + "attn.in_proj_weight"] = _normal(seed, "t." + p + "attn.in_proj_weight", (3 * D, D), D ** -0.5)
+        w[p + "attn.in_proj_bias"] = _normal(seed, "t." + p + "attn.in_proj_bias", (3 * D,), 0.02)
+        w[p + "attn.out_proj.weight"] = _normal(seed, "t." + p + "attn.out_proj.weight", (D, D), proj_std)
+        w[p + "attn.out_proj.bias"] = _normal(seed, "t." + p + "attn.out_proj.bias", (D,), 0.02)
+        w[p + "mlp.c_fc.weight"] = _normal(seed, "t." + p + "mlp.c_fc.weight", (M, D), (2 * D) ** -0.5)
+        w[p + "mlp.c_fc.bias"] = _normal(seed, "t." + p + "mlp.c_fc.bias", (M,), 0.02)
+        w[p + "mlp.c_proj.weight"] = _normal(seed, "t." + p + "mlp.c_proj.weight", (D, M), proj_std)
+        w[p + "mlp.c_proj.bias"] = _normal(seed, "t." + p + "mlp.c_proj.bias", (D,), 0.02)
+    w["ln_final.weight"] = _normal(seed, "t.ln_final.weight", (D,), 0.1, 1.0)
+    w["ln_final.bias"] = _normal(seed, "t.ln_final.bias", (D,), 0.05)
+    w["text_projection"] = _normal(seed, "t.text_projection", (D, E), D ** -0.5)
+    return w
+
+
+def make_token_ids(cfg: TextConfig, n_seq: int, seed: int = 11) -> np.ndarray:
+    """[n_seq, context_length] int32 rows shaped like the CLIP tokenizer's output: SOT, body, EOT (= the largest id), zero padding."""
+    g = _rng(seed, f"tokens.{cfg.name}.{n_seq}")
+    ids = np.zeros((n_seq, cfg.context_length), np.int32)
+    sot, eot = cfg.vocab_size - 2, cfg.vocab_size - 1
+    for i in range(n_seq):
+        n_body = int(g.integers(1, cfg.context_length - 1))
+        ids[i, 0] = sot
+        ids[i, 1:1 + n_body] = g.integers(1, cfg.vocab_size - 2, n_body)
+        ids[i, 1 + n_body] = eot
+    return ids
+
+
 def make_text_features(num_queries: int, embed_dim: int, seed: int = 7) -> np.ndarray:
     """Unit-norm rows standing in for the prompt-ensembled text embeddings
     (reference segmentor.py:157-174 produces ``query_features [Q, E]``)."""

@@ -199,6 +199,19 @@ int sg_op_attention(const float* qkv, int B, int N, int D, int H, int variant, c
  *   input [B,C,h+d-1,w+d-1], filters [B,h,w,d,d] -> out [B,C,h,w], all f32. */
 int sg_adaptive_conv(const float* input, const float* filters, int B, int C, int h, int w, int d, float* out, sg_stream s);
 
+/* ---- CLIP text tower (init-time producer of query_features) -------------------------------------
+ * sg_text_encode replaces CLIP.encode_text(tokens) (open_clip/model.py:288-306): token + positional embedding, causal
+ * residual blocks, ln_final, EOT pooling (argmax of the ids), @ text_projection.  Tensor names = the text part of the CLIP
+ * state dict ("token_embedding.weight", "positional_embedding", "transformer.resblocks.N.*", "ln_final.*", "text_projection").
+ *   tokens int32 [n_seq, context_length] -> out [n_seq, E] f32 (not normalised). */
+typedef struct sg_text sg_text;
+int  sg_text_create(sg_text** out, int device, int width, int layers, int heads, int context_length, int vocab_size, int embed_dim,
+                    int quick_gelu, int precision);
+void sg_text_destroy(sg_text* t);
+int  sg_text_set_tensor(sg_text* t, const char* name, const float* dev_f32, int64_t numel, sg_stream s);
+size_t sg_text_workspace_bytes(const sg_text* t, int n_seq);
+int  sg_text_encode(sg_text* t, const int32_t* tokens, int n_seq, float* out, void* workspace, size_t workspace_bytes, sg_stream s);
+
 /* JBU context.  sg_jbu_create replaces get_upsampler(name, dim) (upsamplers.py:353-369; kind 0 = 'jbu_one', 1 = 'jbu_stack');
  * sg_jbu_set_tensor takes the tensors by their state-dict names ("up.range_temp", "up2.fixup_proj.0.weight",
  * "fixup_proj.1.weight" ...), i.e. load_state_dict (segmentor.py:281-283);

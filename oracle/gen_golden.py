@@ -3,7 +3,7 @@
 deterministic synthetic weights and inputs.  Runs only in the build container; the fixtures are
 data (inputs' seeds + expected outputs), never reference source.
 
-    python -m oracle.gen_golden [--only tiny|refine|jbu|segment|real]
+    python -m oracle.gen_golden [--only tiny|refine|jbu|segment|text|real]
 
 Every fixture is cross-checked here against the build's own CPU restatement (oracle/*.py) so a
 drift between the two fails at mint time, and again in tests/test_oracle_vs_golden.py.
@@ -366,6 +366,32 @@ def gen_segment():
 
 
 # ---------------------------------------------------------------------------------------------
+def gen_text():
+    """text_<cfg>.npz: the reference's CLIP.encode_text on synthetic text weights + tokenizer-shaped ids."""
+    from oracle import text as OT
+    M = R.ref("open_clip.model")
+    for name, S in (("tiny-text", 9), ("tiny-text-gelu", 5)):
+        tc = Wt.TEXT_CONFIGS[name]
+        wnp = Wt.make_text_weights(tc, seed=0)
+        vis = M.CLIPVisionCfg(layers=1, width=32, head_width=16, patch_size=8, image_size=16)
+        txt = M.CLIPTextCfg(context_length=tc.context_length, vocab_size=tc.vocab_size, width=tc.width, heads=tc.heads, layers=tc.layers)
+        net = M.CLIP(tc.embed_dim, vis, txt, quick_gelu=tc.quick_gelu).eval()
+        sd = net.state_dict()
+        for k, v in wnp.items():
+            assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
+            sd[k] = torch.from_numpy(v.copy())
+        net.load_state_dict(sd, strict=True)
+        ids = Wt.make_token_ids(tc, S)
+        ids[1, 3] = ids[1].max()                       # a duplicated maximum: argmax must take the first
+        with torch.no_grad():
+            ref = net.encode_text(torch.from_numpy(ids).long())
+            refn = net.encode_text(torch.from_numpy(ids).long(), normalize=True)
+        mine = OT.encode_text(wnp, tc, ids)
+        close(mine, ref, 2e-5, f"text {name}")
+        close(OT.encode_text(wnp, tc, ids, normalize=True), refn, 2e-5, f"text {name} normalized")
+        save(f"text_{name}", tokens=ids, features=ref.numpy(), features_normalized=refn.numpy())
+
+
 def gen_real():
     """Real-size towers: patch-grid logits, CLS logits and argmax maps on seeded tiles
     (inputs are regenerated from the seed on the GPU box; only outputs are stored)."""
@@ -408,7 +434,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    steps = {"tiny": gen_tiny, "refine": gen_refine, "jbu": gen_jbu, "segment": gen_segment, "real": gen_real}
+    steps = {"tiny": gen_tiny, "refine": gen_refine, "jbu": gen_jbu, "segment": gen_segment, "text": gen_text, "real": gen_real}
     for k, fn in steps.items():
         if not a.only or a.only == k:
             fn()

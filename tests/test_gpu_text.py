@@ -1,0 +1,105 @@
+"""HIP text tower (sg_text_encode) vs the golden fixtures minted from the reference's CLIP.encode_text and vs the oracle
+(oracle/text.py) at the real 77-token / 512-wide shape.  Tolerances: f32 1e-4 absolute on O(1) features; bf16 cosine >= 0.999."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clip_decontamination_amd import weights as Wt            # noqa: E402
+from oracle import text as OT                                  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+
+
+def tower(name, precision):
+    from clip_decontamination_amd.engine import HipTextTower
+    tc = Wt.TEXT_CONFIGS[name]
+    return tc, HipTextTower(tc, Wt.make_text_weights(tc, seed=0), precision=precision, device="cuda:0")
+
+
+@pytest.mark.parametrize("name", ["tiny-text", "tiny-text-gelu"])
+def test_text_golden_f32(golden, name):
+    g = golden(f"text_{name}")
+    tc, tt = tower(name, "f32")
+    ids = torch.from_numpy(g["tokens"])
+    out = tt.encode_text(ids).cpu()
+    assert (out - torch.from_numpy(g["features"])).abs().max().item() < 1e-4
+    outn = tt.encode_text(ids, normalize=True).cpu()
+    assert (outn - torch.from_numpy(g["features_normalized"])).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny-text", "tiny-text-gelu"])
+def test_text_golden_bf16(golden, name):
+    g = golden(f"text_{name}")
+    tc, tt = tower(name, "bf16")
+    out = tt.encode_text(torch.from_numpy(g["tokens"])).cpu()
+    cos = F.cosine_similarity(out, torch.from_numpy(g["features"]), dim=-1)
+    assert cos.min().item() > 0.999, cos
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", None)])
+def test_text_real_shape_vs_oracle(prec, tol):
+    """ViT-B/16's text tower (512 wide, 12 layers, 77 tokens, 49408 ids) on 24 tokenizer-shaped rows."""
+    tc, tt = tower("ViT-B-16", prec)
+    ids = Wt.make_token_ids(tc, 24)
+    out = tt.encode_text(torch.from_numpy(ids)).cpu()
+    with torch.no_grad():
+        ref = OT.encode_text(Wt.make_text_weights(tc, seed=0), tc, ids)
+    if tol is not None:
+        assert (out - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    else:
+        assert F.cosine_similarity(out, ref, dim=-1).min().item() > 0.998
+
+
+def test_causality_and_padding_independence():
+    """Changing ids AFTER the EOT position must not change the pooled feature (causal mask), changing one before must."""
+    tc, tt = tower("tiny-text", "f32")
+    ids = Wt.make_token_ids(tc, 4)
+    base = tt.encode_text(torch.from_numpy(ids)).cpu()
+    ids2 = ids.copy()
+    for i in range(4):
+        e = int(ids[i].argmax())
+        ids2[i, e + 1:] = 1                                        # still below the EOT id
+    assert torch.equal(tt.encode_text(torch.from_numpy(ids2)).cpu(), base)
+    ids3 = ids.copy(); ids3[:, 1] = (ids3[:, 1] + 1) % (tc.vocab_size - 3) + 1
+    assert (tt.encode_text(torch.from_numpy(ids3)).cpu() - base).abs().max().item() > 1e-3
+
+
+def test_query_features_ensemble_and_segmentor_route(tmp_path):
+    """The reference's init route (segmentor.py:157-174): tokenizer -> encode_text -> normalise / mean / normalise."""
+    from clip_decontamination_amd.prompts import ensemble_prompts
+    import zlib
+    tc, tt = tower("tiny-8", "f32")
+
+    def tokenizer(texts):                                           # stand-in for the BPE tokenizer: deterministic ids, SOT / EOT framing
+        rows = np.zeros((len(texts), tc.context_length), np.int64)
+        for r, s in enumerate(texts):
+            words = s.split()[: tc.context_length - 2]
+            rows[r, 0] = tc.vocab_size - 2
+            for j, wd in enumerate(words):
+                rows[r, 1 + j] = 1 + zlib.crc32(wd.encode()) % (tc.vocab_size - 3)
+            rows[r, 1 + len(words)] = tc.vocab_size - 1
+        return torch.from_numpy(rows)
+
+    words = ["building", "road", "water"]
+    q = tt.query_features(tokenizer, words).cpu()
+    with torch.no_grad():
+        ref = OT.query_features(Wt.make_text_weights(tc, seed=0), tc, [tokenizer(ensemble_prompts(w)) for w in words])
+    assert (q - ref).abs().max().item() < 1e-4
+    # through the drop-in constructor, with a checkpoint holding both towers
+    vcfg = Wt.vit_config("tiny-8")
+    sd = {"visual." + k: v for k, v in Wt.make_vit_weights(vcfg, seed=0).items()}
+    sd.update(Wt.make_text_weights(tc, seed=0))
+    ck = tmp_path / "clip.npz"
+    np.savez(ck, **sd)
+    names = tmp_path / "cls.txt"
+    names.write_text("building\nroad\nwater,river\n")
+    from segmentor import SegmentorEx
+    seg = SegmentorEx("CLIP", "tiny-8", "SegEarth", str(names), device="cuda:0", checkpoint=str(ck), tokenizer=tokenizer, precision="f32")
+    assert seg.query_features.shape == (4, tc.embed_dim) and seg.query_idx.tolist() == [0, 1, 2, 2]
+    assert (seg.query_features[:2].cpu() - ref[:2]).abs().max().item() < 1e-4
+    assert seg.net.encode_text(tokenizer(["a photo of a road."])).shape == (1, tc.embed_dim)

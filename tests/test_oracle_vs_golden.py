@@ -192,3 +192,16 @@ def test_real_size_b16_224(golden):
             lg = o.forward_feature(img, (14, 14))[0]
         assert maxdiff(lg, g[f"ViT-B-16.224.{mt}.logits"]) < 1e-4
         assert torch.equal(lg.argmax(0).to(torch.uint8), t(g[f"ViT-B-16.224.{mt}.argmax"]))
+
+
+@pytest.mark.parametrize("name", ["tiny-text", "tiny-text-gelu"])
+def test_text_tower(golden, name):
+    """oracle/text.py vs the reference's CLIP.encode_text (open_clip/model.py:288-306)."""
+    from oracle import text as OT
+    g = golden(f"text_{name}")
+    tc = Wt.TEXT_CONFIGS[name]
+    w = Wt.make_text_weights(tc, seed=0)
+    with torch.no_grad():
+        assert maxdiff(OT.encode_text(w, tc, g["tokens"]), g["features"]) < TOL
+        assert maxdiff(OT.encode_text(w, tc, g["tokens"], normalize=True), g["features_normalized"]) < TOL
+    assert (g["tokens"] == Wt.make_token_ids(tc, g["tokens"].shape[0]))[0].all()      # ids regenerate from the seed
