@@ -37,7 +37,7 @@ from clip_decontamination_amd import weights as Wt                      # noqa: 
 
 POTSDAM_QIDX = [0, 0, 1, 2, 3, 4, 5, 5]      # configs/cls_potsdam.txt: 8 queries -> 6 classes
 TILE, STRIDE = 512, 256
-TILE_COLS, TILE_ROWS_PER_RANK = 8, 8         # 64 tiles per rank per step
+TILE_COLS, TILE_ROWS_PER_RANK = 16, 8        # default: 128 tiles per rank per step (a 2304 x 4352 scene band)
 PEAK_BF16_TFLOPS = 2500.0                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -81,12 +81,15 @@ def cpu_baseline(cfg, n_tiles=3):
 
 
 def main():
+    global TILE_COLS, TILE_ROWS_PER_RANK
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--tiles-per-launch", type=int, default=64)
+    ap.add_argument("--tile-cols", type=int, default=TILE_COLS, help="tiles per scene row")
+    ap.add_argument("--tile-rows", type=int, default=TILE_ROWS_PER_RANK, help="tile rows per rank (weak scaling: the scene grows with the ranks)")
+    ap.add_argument("--tiles-per-launch", type=int, default=0, help="0 = all of a rank's tiles in one launch of the tower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -115,6 +118,9 @@ def main():
     from clip_decontamination_amd import _lib, ops
     from clip_decontamination_amd.pipeline import tile_windows
     lib = _lib.load()
+    TILE_COLS, TILE_ROWS_PER_RANK = args.tile_cols, args.tile_rows
+    if args.tiles_per_launch <= 0:
+        args.tiles_per_launch = TILE_COLS * TILE_ROWS_PER_RANK
     cfg, pipe = build_pipeline(device, args.precision, args.tiles_per_launch)
 
     # scene: TILE_COLS x (TILE_ROWS_PER_RANK * world) tiles of 512 at stride 256, uint8 NHWC, resident in HBM
@@ -136,10 +142,10 @@ def main():
     up = (TILE + t + b, TILE + l + r)
 
     def step():
-        tl = pipe.tile_logits(slab, my_local, (TILE, TILE))           # [64, Q, 37, 37]
+        tl = pipe.tile_logits(slab, my_local, (TILE, TILE))           # [tiles of this rank, Q, 37, 37]
         if world > 1:
             gathered = [torch.empty_like(tl) for _ in range(world)]
-            dist.all_gather(gathered, tl)                             # RCCL over xGMI: 2.8 MB per rank
+            dist.all_gather(gathered, tl)                             # RCCL over xGMI: 44 kB per tile
             tl_all = torch.cat(gathered, 0)
         else:
             tl_all = tl

@@ -61,6 +61,9 @@ SIGNATURES = {
     "sg_outlier_suppress": (I, [P, P, P, I, I, I, I, I, F, P, P, P]),
     "sg_cross_tile_scratch_bytes": (Z, [I, I, I, I, I]),
     "sg_cross_tile_fusion": (I, [P, I, I, I, I, I, I, I, F, P, P]),
+    "sg_cross_tile_pack": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
+    "sg_cross_tile_fuse": (I, [P, P, I, I, I, I, I, I, I, I, F, I, P, P]),
+    "sg_cross_tile_apply": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "sg_weak_token_replace": (I, [P, P, I, I, I, I, I, P, P, P]),
     "sg_similarity_map": (I, [P, L, I, I, I, I, F, I, I, P, P, Z, P]),
     "sg_op_linear": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),

@@ -227,17 +227,33 @@ int attn_mode_enhance(float* tokens, int64_t sb, int64_t st, float* A, int B, in
 // Neither depends on another tile's top result (gh >= 2 bw), so every strip of a scene is fused in parallel:
 // one workgroup per (tile, direction) writes its strip to scratch, a second launch scatters.
 constexpr int CTF_MAX_STRIP = 128;
+// Under tile sharding the neighbour may live on another rank, so neighbour strips always come from PACKED
+// strip buffers indexed by the GLOBAL tile id ([T, S, C]); the tokens / results are local ([n_local, ...], first tile = tile0).
+//   pack 0: ORIGINAL right columns  (gh x bw)          pack 1: FINAL bottom rows (bw x gw; columns [0,bw) from the tile's left result)
+__global__ void ctf_pack_kernel(const float* __restrict__ tokens, const float* __restrict__ left_result, int tile0, int wg, int gh, int gw,
+                                int C, int bw, int which, float* __restrict__ out) {
+  const int i_loc = blockIdx.y;
+  const int S = which == 0 ? gh * bw : bw * gw;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)S * C) return;
+  const int c = (int)(i % C), e = (int)(i / C);
+  const int n = gh * gw;
+  const float* t = tokens + (int64_t)i_loc * n * C;
+  float v;
+  if (which == 0) v = t[(int64_t)((e / bw) * gw + (gw - bw) + (e % bw)) * C + c];
+  else {
+    const int col = e % gw, row = gh - bw + e / gw;
+    if (col < bw && left_result && ((tile0 + i_loc) % wg) > 0) v = left_result[((int64_t)i_loc * gh * bw + row * bw + col) * C + c];
+    else v = t[(int64_t)(row * gw + col) * C + c];
+  }
+  out[(int64_t)i_loc * S * C + i] = v;
+}
 
-struct StripView {           // strip element e (0..len) -> token row pointer
-  const float* base; int a_stride, b_stride, b_len, offset;   // token index = offset + (e / b_len) * a_stride + (e % b_len) * b_stride
-  __device__ __forceinline__ int tok(int e) const { return offset + (e / b_len) * a_stride + (e % b_len) * b_stride; }
-};
-
-__global__ __launch_bounds__(256) void ctf_fuse_kernel(const float* __restrict__ tokens, const float* __restrict__ left_scratch, int hg,
-                                                       int wg, int gh, int gw, int C, int bw, int mode, float strength, int pass,
-                                                       float* __restrict__ out_scratch) {
+__global__ __launch_bounds__(256) void ctf_fuse_kernel(const float* __restrict__ tokens, const float* __restrict__ nbr_strips, int tile0, int wg,
+                                                       int gh, int gw, int C, int bw, int mode, float strength, int pass,
+                                                       float* __restrict__ result) {
   extern __shared__ float sm[];
-  const int tile = blockIdx.x, hi = tile / wg, wi = tile % wg;
+  const int i_loc = blockIdx.x, tile = tile0 + i_loc, hi = tile / wg, wi = tile % wg;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = gh * gw;
   const bool is_left = pass == 0;
@@ -247,20 +263,11 @@ __global__ __launch_bounds__(256) void ctf_fuse_kernel(const float* __restrict__
   const int L2 = mode == 0 ? S : 2 * S;
   float* rn_cur = sm + S * L2;                                // [S] norms / row scalars
   float* rn_nbr = rn_cur + S;
-  const float* cur_t = tokens + (int64_t)tile * n * C;
+  const float* cur_t = tokens + (int64_t)i_loc * n * C;
   const int nb_tile = is_left ? tile - 1 : tile - wg;
-  const float* nbr_t = tokens + (int64_t)nb_tile * n * C;
-  // element e of the current / neighbour strip -> patch index inside its tile
+  const float* nbr_s = nbr_strips + (int64_t)nb_tile * S * C;
   auto cur_idx = [&](int e) { return is_left ? (e / bw) * gw + (e % bw) : e; };                        // left cols | top rows
-  auto nbr_idx = [&](int e) { return is_left ? (e / bw) * gw + (gw - bw) + (e % bw) : (gh - bw) * gw + e; };   // right cols | bottom rows
-  // the upper neighbour's bottom rows are FINAL: its own left result replaces columns [0,bw)
-  auto nbr_row = [&](int e) -> const float* {
-    if (!is_left && (nb_tile % wg) > 0) {
-      const int col = e % gw, row = gh - bw + e / gw;
-      if (col < bw) return left_scratch + ((int64_t)nb_tile * gh * bw + row * bw + col) * C;
-    }
-    return nbr_t + (int64_t)nbr_idx(e) * C;
-  };
+  auto nbr_row = [&](int e) -> const float* { return nbr_s + (int64_t)e * C; };
   const float eps = 1e-6f;
   for (int e = wave; e < S; e += 4) {                         // norms (weighted mode)
     const float* x = cur_t + (int64_t)cur_idx(e) * C; const float* y = nbr_row(e);
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void ctf_fuse_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  float* dst = out_scratch + (int64_t)tile * S * C;
+  float* dst = result + (int64_t)i_loc * S * C;
   for (int p = tid; p < S * C; p += 256) {                    // blended strip
     const int i = p / C, c = p % C;
     const float* w = sim + i * L2;
@@ -315,15 +322,39 @@ __global__ __launch_bounds__(256) void ctf_fuse_kernel(const float* __restrict__
   }
 }
 
-__global__ void ctf_apply_kernel(float* __restrict__ tokens, const float* __restrict__ left_scratch, const float* __restrict__ top_scratch,
-                                 int hg, int wg, int gh, int gw, int C, int bw) {
-  const int tile = blockIdx.y, hi = tile / wg, wi = tile % wg;
+__global__ void ctf_apply_kernel(float* __restrict__ tokens, const float* __restrict__ left_result, const float* __restrict__ top_result,
+                                 int tile0, int wg, int gh, int gw, int C, int bw) {
+  const int i_loc = blockIdx.y, tile = tile0 + i_loc, hi = tile / wg, wi = tile % wg;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = gh * gw;
   if (i >= (int64_t)n * C) return;
   const int c = (int)(i % C), p = (int)(i / C), row = p / gw, col = p % gw;
-  if (wi > 0 && col < bw) tokens[(int64_t)tile * n * C + i] = left_scratch[((int64_t)tile * gh * bw + row * bw + col) * C + c];
-  else if (hi > 0 && row < bw) tokens[(int64_t)tile * n * C + i] = top_scratch[((int64_t)tile * bw * gw + row * gw + col) * C + c];
+  if (wi > 0 && col < bw) tokens[(int64_t)i_loc * n * C + i] = left_result[((int64_t)i_loc * gh * bw + row * bw + col) * C + c];
+  else if (hi > 0 && row < bw) tokens[(int64_t)i_loc * n * C + i] = top_result[((int64_t)i_loc * bw * gw + row * gw + col) * C + c];
+}
+
+static int ctf_check(int gh, int gw, int C, int bw, const char* who) {
+  SG_REQUIRE(gh > 0 && gw > 0 && C > 0 && bw > 0, "%s: bad shape", who);
+  SG_REQUIRE(gh >= 2 * bw && gw >= 2 * bw, "%s: patch grid %dx%d too small for boundary width %d", who, gh, gw, bw);
+  SG_REQUIRE(gh * bw <= CTF_MAX_STRIP && gw * bw <= CTF_MAX_STRIP, "%s: strips longer than %d tokens", who, CTF_MAX_STRIP);
+  return SG_OK;
+}
+static int ctf_pack(const float* tokens, const float* left_result, int n_local, int tile0, int wg, int gh, int gw, int C, int bw, int which,
+                    float* out, hipStream_t s) {
+  const int S = which == 0 ? gh * bw : bw * gw;
+  hipLaunchKernelGGL(ctf_pack_kernel, dim3((unsigned)cdiv((int64_t)S * C, 256), (unsigned)n_local), dim3(256), 0, s, tokens, left_result, tile0, wg,
+                     gh, gw, C, bw, which, out);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+static int ctf_fuse(const float* tokens, const float* nbr_strips, int n_local, int tile0, int wg, int gh, int gw, int C, int bw, int mode,
+                    float strength, int pass, float* result, hipStream_t s) {
+  const int S = pass == 0 ? gh * bw : bw * gw;
+  const size_t lds = ((size_t)S * (mode == 0 ? S : 2 * S) + 2 * S) * sizeof(float);
+  if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ctf_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ctf_fuse_kernel, dim3(n_local), dim3(256), lds, s, tokens, nbr_strips, tile0, wg, gh, gw, C, bw, mode, strength, pass, result);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
 }
 
 }  // namespace sg
@@ -331,28 +362,52 @@ __global__ void ctf_apply_kernel(float* __restrict__ tokens, const float* __rest
 using namespace sg;
 
 extern "C" size_t sg_cross_tile_scratch_bytes(int T, int gh, int gw, int C, int bw) {
-  return ((size_t)T * gh * bw * C + (size_t)T * bw * gw * C) * sizeof(float) + 512;
+  const size_t sl = (size_t)T * gh * bw * C, st = (size_t)T * bw * gw * C;
+  return (sl + st + (sl > st ? sl : st)) * sizeof(float) + 512;
 }
 
 extern "C" int sg_cross_tile_fusion(float* tokens, int hg, int wg, int gh, int gw, int C, int bw, int mode, float strength, void* scratch,
                                     sg_stream st) {
   SG_REQUIRE(tokens && scratch, "sg_cross_tile_fusion: null pointer");
-  SG_REQUIRE(hg > 0 && wg > 0 && gh > 0 && gw > 0 && C > 0 && bw > 0, "sg_cross_tile_fusion: bad shape");
-  SG_REQUIRE(gh >= 2 * bw && gw >= 2 * bw, "sg_cross_tile_fusion: patch grid %dx%d too small for boundary width %d", gh, gw, bw);
-  SG_REQUIRE(gh * bw <= CTF_MAX_STRIP && gw * bw <= CTF_MAX_STRIP, "sg_cross_tile_fusion: strips longer than %d tokens", CTF_MAX_STRIP);
+  SG_REQUIRE(hg > 0 && wg > 0, "sg_cross_tile_fusion: bad tile grid");
+  SG_TRY(ctf_check(gh, gw, C, bw, "sg_cross_tile_fusion"));
   SG_REQUIRE(mode == 0 || mode == 1, "sg_cross_tile_fusion: mode must be 0 (weighted) or 1 (attention)");
   hipStream_t s = as_stream(st);
   const int T = hg * wg;
   float* left = reinterpret_cast<float*>(scratch);
   float* top = left + (size_t)T * gh * bw * C;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int S = pass == 0 ? gh * bw : bw * gw;
-    const size_t lds = ((size_t)S * (mode == 0 ? S : 2 * S) + 2 * S) * sizeof(float);
-    if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ctf_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ctf_fuse_kernel, dim3(T), dim3(256), lds, s, tokens, left, hg, wg, gh, gw, C, bw, mode, strength, pass, pass == 0 ? left : top);
-    SG_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(ctf_apply_kernel, dim3((unsigned)cdiv((int64_t)gh * gw * C, 256), (unsigned)T), dim3(256), 0, s, tokens, left, top, hg, wg, gh, gw, C, bw);
+  float* strips = top + (size_t)T * bw * gw * C;
+  SG_TRY(ctf_pack(tokens, nullptr, T, 0, wg, gh, gw, C, bw, 0, strips, s));
+  SG_TRY(ctf_fuse(tokens, strips, T, 0, wg, gh, gw, C, bw, mode, strength, 0, left, s));
+  SG_TRY(ctf_pack(tokens, left, T, 0, wg, gh, gw, C, bw, 1, strips, s));
+  SG_TRY(ctf_fuse(tokens, strips, T, 0, wg, gh, gw, C, bw, mode, strength, 1, top, s));
+  hipLaunchKernelGGL(ctf_apply_kernel, dim3((unsigned)cdiv((int64_t)gh * gw * C, 256), (unsigned)T), dim3(256), 0, s, tokens, left, top, 0, wg, gh, gw, C, bw);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// The three steps of the fusion for a rank that holds tiles [tile0, tile0 + n_local) of the raster list; the caller exchanges the
+// packed strips between the steps (two small all-gathers):
+//   pack(0) -> gather -> fuse(0) -> pack(1, left_result) -> gather -> fuse(1) -> apply
+extern "C" int sg_cross_tile_pack(const float* tokens, const float* left_result, int n_local, int tile0, int wg, int gh, int gw, int C, int bw,
+                                  int which, float* out, sg_stream st) {
+  SG_REQUIRE(tokens && out && n_local > 0 && tile0 >= 0 && wg > 0 && (which == 0 || which == 1), "sg_cross_tile_pack: bad arguments");
+  SG_TRY(ctf_check(gh, gw, C, bw, "sg_cross_tile_pack"));
+  return ctf_pack(tokens, left_result, n_local, tile0, wg, gh, gw, C, bw, which, out, as_stream(st));
+}
+extern "C" int sg_cross_tile_fuse(const float* tokens, const float* nbr_strips, int n_local, int tile0, int wg, int gh, int gw, int C, int bw,
+                                  int mode, float strength, int pass, float* result, sg_stream st) {
+  SG_REQUIRE(tokens && nbr_strips && result && n_local > 0 && tile0 >= 0 && wg > 0 && (pass == 0 || pass == 1) && (mode == 0 || mode == 1),
+             "sg_cross_tile_fuse: bad arguments");
+  SG_TRY(ctf_check(gh, gw, C, bw, "sg_cross_tile_fuse"));
+  return ctf_fuse(tokens, nbr_strips, n_local, tile0, wg, gh, gw, C, bw, mode, strength, pass, result, as_stream(st));
+}
+extern "C" int sg_cross_tile_apply(float* tokens, const float* left_result, const float* top_result, int n_local, int tile0, int wg, int gh,
+                                   int gw, int C, int bw, sg_stream st) {
+  SG_REQUIRE(tokens && left_result && top_result && n_local > 0 && tile0 >= 0 && wg > 0, "sg_cross_tile_apply: bad arguments");
+  SG_TRY(ctf_check(gh, gw, C, bw, "sg_cross_tile_apply"));
+  hipLaunchKernelGGL(ctf_apply_kernel, dim3((unsigned)cdiv((int64_t)gh * gw * C, 256), (unsigned)n_local), dim3(256), 0, as_stream(st), tokens,
+                     left_result, top_result, tile0, wg, gh, gw, C, bw);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

@@ -222,3 +222,38 @@ def cross_tile_fusion(tokens, hg: int, wg: int, gh: int, gw: int, boundary_width
     check(lib.sg_cross_tile_fusion(ptr(tokens), hg, wg, gh, gw, Cc, boundary_width, 0 if fusion_mode == "weighted" else 1,
                                    float(fusion_strength), sp, stream_ptr()), "sg_cross_tile_fusion")
     return tokens
+
+
+class CrossTileSteps:
+    """The three device steps of the sharded cross-tile fusion (sg_cross_tile_pack / _fuse / _apply) for a rank holding tiles
+    [tile0, tile0+n_local) of a scene whose tile grid is ``wg`` wide.  ``pipeline.sharded_cross_tile_fusion`` drives them and
+    does the two strip all-gathers in between; the CPU tests replace this class with a torch stand-in."""
+
+    def __init__(self, gh: int, gw: int, C_: int, boundary_width: int, fusion_mode: str, fusion_strength: float, wg: int):
+        self.lib = _lib.load()
+        self.gh, self.gw, self.C, self.bw, self.wg = gh, gw, C_, boundary_width, wg
+        self.mode = 0 if fusion_mode == "weighted" else 1
+        self.strength = float(fusion_strength)
+
+    def strip_len(self, which: int) -> int:
+        return self.gh * self.bw if which == 0 else self.bw * self.gw
+
+    def pack(self, tokens, tile0: int, which: int, left_result=None):
+        _require_gpu(tokens, left_result)
+        out = torch.empty(tokens.shape[0], self.strip_len(which), self.C, dtype=torch.float32, device=tokens.device)
+        check(self.lib.sg_cross_tile_pack(ptr(tokens), ptr(left_result), tokens.shape[0], tile0, self.wg, self.gh, self.gw, self.C, self.bw,
+                                          which, ptr(out), stream_ptr()), "sg_cross_tile_pack")
+        return out
+
+    def fuse(self, tokens, tile0: int, nbr_strips, which: int):
+        _require_gpu(tokens, nbr_strips)
+        res = torch.zeros(tokens.shape[0], self.strip_len(which), self.C, dtype=torch.float32, device=tokens.device)
+        check(self.lib.sg_cross_tile_fuse(ptr(tokens), ptr(nbr_strips), tokens.shape[0], tile0, self.wg, self.gh, self.gw, self.C, self.bw,
+                                          self.mode, self.strength, which, ptr(res), stream_ptr()), "sg_cross_tile_fuse")
+        return res
+
+    def apply(self, tokens, tile0: int, left_result, top_result):
+        _require_gpu(tokens, left_result, top_result)
+        check(self.lib.sg_cross_tile_apply(ptr(tokens), ptr(left_result), ptr(top_result), tokens.shape[0], tile0, self.wg, self.gh, self.gw,
+                                           self.C, self.bw, stream_ptr()), "sg_cross_tile_apply")
+        return tokens

@@ -38,6 +38,42 @@ def partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def gather_blocks(local: torch.Tensor, n_items: int, world: int, rank: int, group=None) -> torch.Tensor:
+    """All-gather of per-rank blocks of the raster tile list (``partition``): ``local`` holds this rank's items (possibly followed
+    by padding); returns the full [n_items, ...] list on every rank.  Blocks are padded to ceil(n_items / world) so the
+    collective is fixed-size (RCCL over xGMI on GPUs)."""
+    lo, hi = partition(n_items, world, rank)
+    t_pad = (n_items + world - 1) // world
+    block = local.new_zeros((t_pad,) + tuple(local.shape[1:]))
+    block[:hi - lo] = local[:hi - lo]
+    gathered = [torch.empty_like(block) for _ in range(world)]
+    torch.distributed.all_gather(gathered, block, group=group)
+    parts = []
+    for r in range(world):
+        a, b = partition(n_items, world, r)
+        parts.append(gathered[r][:b - a])
+    return torch.cat(parts, 0)
+
+
+def sharded_cross_tile_fusion(tokens: torch.Tensor, steps, n_tiles: int, world: int, rank: int, group=None) -> torch.Tensor:
+    """Cross-tile boundary fusion when the raster tile list is partitioned over ranks.  ``tokens`` [n_local, n, C]
+    are this rank's PRE-fusion patch tokens; a tile needs the right columns of its left neighbour and the final bottom rows of
+    its upper neighbour, which may live on another rank: two all-gathers of packed strips (a few hundred kB per tile edge)
+    replace the reference's per-process boundary cache.  ``steps`` = ops.CrossTileSteps (or a stand-in with pack/fuse/apply)."""
+    lo, hi = partition(n_tiles, world, rank)
+    assert tokens.shape[0] == hi - lo
+    if hi == lo:                                   # more ranks than tiles: still take part in the collectives
+        dummy = tokens.new_zeros((0, steps.strip_len(0), tokens.shape[-1]))
+        gather_blocks(dummy, n_tiles, world, rank, group)
+        gather_blocks(tokens.new_zeros((0, steps.strip_len(1), tokens.shape[-1])), n_tiles, world, rank, group)
+        return tokens
+    right_all = gather_blocks(steps.pack(tokens, lo, 0), n_tiles, world, rank, group)
+    left_res = steps.fuse(tokens, lo, right_all, 0)
+    bottom_all = gather_blocks(steps.pack(tokens, lo, 1, left_res), n_tiles, world, rank, group)
+    top_res = steps.fuse(tokens, lo, bottom_all, 1)
+    return steps.apply(tokens, lo, left_res, top_res)
+
+
 class SegPipeline:
     def __init__(self, net: HipCLIP, text: torch.Tensor, query_idx: torch.Tensor, model_type: str = "SegEarth",
                  ignore_residual: bool = True, cls_token_lambda: float = 0.0, global_debias_factor: float = 0.0,
@@ -124,12 +160,10 @@ class SegPipeline:
             world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
         hg = max(H - crop[0] + stride[0] - 1, 0) // stride[0] + 1
         wg = max(W - crop[1] + stride[1] - 1, 0) // stride[1] + 1
-        if world > 1 and self.cross_tile_fusion is not None:
-            raise NotImplementedError("cross-tile fusion under tile sharding needs a strip exchange between ranks (SURVEY.md §8e); not built")
         if world == 1:
             tl = self.tile_logits(scene, wins, tile_hw, grid_of_tiles=(hg, wg))
         else:
-            tl = self.gather_tile_logits(scene, wins, tile_hw, world, rank, group)
+            tl = self.gather_tile_logits(scene, wins, tile_hw, world, rank, group, grid_of_tiles=(hg, wg))
         win_dev = torch.tensor(wins, dtype=torch.int32, device=self.device)
         if self.upsampler is not None:
             up_hw_src = up_hw           # per-pixel logits: the bilinear resize inside stitch is the identity
@@ -140,25 +174,45 @@ class SegPipeline:
             canvas = ops.resize_bilinear(canvas, tuple(ori_shape))
         return canvas.unsqueeze(0)
 
-    def gather_tile_logits(self, scene, wins, tile_hw, world, rank, group=None) -> torch.Tensor:
+    def gather_tile_logits(self, scene, wins, tile_hw, world, rank, group=None, grid_of_tiles=None) -> torch.Tensor:
         """Rank r computes a contiguous block of the raster tile list; one all-gather (RCCL over xGMI on GPUs)
-        of equal-sized [T_pad, Q, gh, gw] blocks rebuilds the full list on every rank."""
+        of equal-sized [T_pad, Q, gh, gw] blocks rebuilds the full list on every rank.  With cross-tile fusion the
+        boundary strips are exchanged first (``sharded_cross_tile_fusion``)."""
         T = len(wins)
         lo, hi = partition(T, world, rank)
-        t_pad = (T + world - 1) // world
         mine = list(wins[lo:hi])
-        if not mine:                                   # more ranks than tiles: compute a dummy so shapes agree
-            mine = [wins[0]]
-        local = self.tile_logits(scene, mine, tile_hw)
-        block = local.new_zeros((t_pad,) + tuple(local.shape[1:]))
-        block[:hi - lo] = local[:hi - lo]
-        gathered = [torch.empty_like(block) for _ in range(world)]
-        torch.distributed.all_gather(gathered, block, group=group)
-        parts = []
-        for r in range(world):
-            a, b = partition(T, world, r)
-            parts.append(gathered[r][:b - a])
-        return torch.cat(parts, 0)
+        fuse = getattr(self, "cross_tile_fusion", None) is not None and grid_of_tiles is not None and T > 1
+        if fuse:
+            local = self._fused_tile_logits(scene, mine if mine else [wins[0]], tile_hw, grid_of_tiles, T, world, rank, group,
+                                            n_real=hi - lo)
+        else:
+            local = self.tile_logits(scene, mine if mine else [wins[0]], tile_hw)   # more ranks than tiles: a dummy so shapes agree
+        return gather_blocks(local, T, world, rank, group)
+
+    def _fused_tile_logits(self, scene, mine, tile_hw, grid_of_tiles, T, world, rank, group, n_real):
+        v = self.visual
+        P = v.cfg.patch
+        l, r, t, b = compute_padsize(tile_hw[0], tile_hw[1], P)
+        gh, gw = (tile_hw[0] + t + b) // P, (tile_hw[1] + l + r) // P
+        if self.upsampler is not None:
+            raise NotImplementedError("cross-tile fusion together with the JBU upsampler is not wired")
+        opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement)
+        win = torch.tensor(list(mine), dtype=torch.int32, device=self.device).reshape(-1, 4)
+        cls_all, tok_all = [], []
+        for i in range(0, win.shape[0], self.tiles_per_launch):
+            c_, t_ = v.forward_tiles(scene, win[i:i + self.tiles_per_launch], tile_hw, opts, None)
+            cls_all.append(c_); tok_all.append(t_)
+        tok = torch.cat(tok_all, 0)[:n_real].contiguous()
+        cls = None if cls_all[0] is None else torch.cat(cls_all, 0)[:n_real].contiguous()
+        cf = self.cross_tile_fusion
+        steps = ops.CrossTileSteps(gh, gw, tok.shape[-1], cf.get("cache_boundary_width", 2), cf.get("fusion_mode", "weighted"),
+                                   cf.get("fusion_strength", 0.3), grid_of_tiles[1])
+        tok = sharded_cross_tile_fusion(tok, steps, T, world, rank, group)
+        if n_real == 0:
+            return tok.new_zeros((0, self.num_queries, gh, gw))
+        lg = ops.cosine_logits(tok, cls, self.text, self.global_debias_factor if cls is not None else 0.0,
+                               self.cls_token_lambda if cls is not None else 0.0)
+        return lg.reshape(n_real, self.num_queries, gh, gw)
 
     # -- reference forward_feature (whole image / explicit logit size) ------------------------------------------
     def forward_feature(self, img: torch.Tensor, logit_size=None) -> torch.Tensor:

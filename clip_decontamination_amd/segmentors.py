@@ -217,7 +217,8 @@ class _HipSegmentorBase(_Base):
                            ignore_residual=self.ignore_residual, cls_token_lambda=self.cls_token_lambda,
                            global_debias_factor=self.global_debias_factor, logit_scale=self.logit_scale, prob_thd=self.prob_thd,
                            bg_idx=self.bg_idx, apply_similarity_enhancement=getattr(self, "apply_similarity_enhancement", False),
-                           upsampler=self.upsampler, tiles_per_launch=self._tiles_per_launch)
+                           upsampler=self.upsampler, tiles_per_launch=self._tiles_per_launch,
+                           cross_tile_fusion=getattr(self, "cross_tile_fusion_cfg", None))
 
     def forward_feature(self, img, logit_size=None, tile_h_idx=None, tile_w_idx=None):
         """Reference segmentor.py:286-392.  img [B,3,H,W] -> logits [B,Q,h,w]."""
@@ -294,7 +295,7 @@ class SegmentorEx(_HipSegmentorBase):
                  similarity_enhancement_cfg=None, result_dir=None, heatmap_dir=None,
                  # -- drop-in extras (see module docstring) --
                  checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
-                 tokenizer=None):
+                 tokenizer=None, cross_tile_fusion_cfg=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
         if model_type == "GEM":
@@ -307,6 +308,8 @@ class SegmentorEx(_HipSegmentorBase):
         visual = self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                              slide_crop, cls_token_lambda, bg_idx, _to_bool(apply_sim_feat_up), sim_feat_up_cfg, global_debias_factor,
                              checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer)
+        # opt-in extra: kwargs of the reference's CrossTileFusion (cross_tile_fusion.py:24-60), which the reference never calls (R2)
+        self.cross_tile_fusion_cfg = cross_tile_fusion_cfg
         self.apply_ctd = False
         self.apply_layer_fusion, self.layer_fusion_lambda, self.layer_fusion_threshold = False, layer_fusion_lambda, layer_fusion_threshold
         self.apply_similarity_enhancement = _to_bool(apply_similarity_enhancement)
@@ -335,7 +338,7 @@ class Segmentor(_HipSegmentorBase):
                  logit_scale=50, slide_stride=112, slide_crop=224, cls_token_lambda=0, bg_idx=0, apply_sim_feat_up=True,
                  sim_feat_up_cfg=dict(model_name="jbu_one", model_path="your/model/path"),
                  checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
-                 tokenizer=None):
+                 tokenizer=None, cross_tile_fusion_cfg=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
         if model_type == "GEM" and cls_token_lambda != 0:
@@ -343,5 +346,7 @@ class Segmentor(_HipSegmentorBase):
         self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                     slide_crop, cls_token_lambda, bg_idx, apply_sim_feat_up, sim_feat_up_cfg, 0.0,
                     checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer)
+        # opt-in extra: kwargs of the reference's CrossTileFusion (cross_tile_fusion.py:24-60), which the reference never calls (R2)
+        self.cross_tile_fusion_cfg = cross_tile_fusion_cfg
         self.output_cls_token = cls_token_lambda != 0
         self.apply_similarity_enhancement = False

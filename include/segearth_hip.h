@@ -168,6 +168,17 @@ int sg_outlier_suppress(float* feats, const float* attn_cls, const float* attn_d
  *   tokens [hg*wg, gh*gw, C] f32 patch tokens of the scene's tiles, updated in place; mode 0 = weighted, 1 = attention. */
 size_t sg_cross_tile_scratch_bytes(int T, int gh, int gw, int C, int bw);
 int sg_cross_tile_fusion(float* tokens, int hg, int wg, int gh, int gw, int C, int bw, int mode, float strength, void* scratch, sg_stream s);
+/* The same fusion for a rank holding tiles [tile0, tile0+n_local) of the raster list: neighbour strips are read
+ * from PACKED buffers indexed by the global tile id, which the caller all-gathers between the steps
+ *   pack(which=0: original right columns [gh*bw,C]) -> gather -> fuse(pass 0) -> pack(which=1: final bottom rows [bw*gw,C],
+ *   columns [0,bw) taken from left_result) -> gather -> fuse(pass 1) -> apply.
+ * tokens / out / result / left_result / top_result are local ([n_local, ...]); nbr_strips is global ([hg*wg, S, C]). */
+int sg_cross_tile_pack(const float* tokens, const float* left_result, int n_local, int tile0, int wg, int gh, int gw, int C, int bw,
+                       int which, float* out, sg_stream s);
+int sg_cross_tile_fuse(const float* tokens, const float* nbr_strips, int n_local, int tile0, int wg, int gh, int gw, int C, int bw,
+                       int mode, float strength, int pass, float* result, sg_stream s);
+int sg_cross_tile_apply(float* tokens, const float* left_result, const float* top_result, int n_local, int tile0, int wg, int gh, int gw,
+                        int C, int bw, sg_stream s);
 /* SelfAttentionEnhancementModule feature mode (self_attention_enhancement.py:71-150,247-324) */
 int sg_weak_token_replace(float* feats, const float* attn_diag, int B, int gh, int gw, int D, int top_k,
                           int32_t* out_idx, void* scratch, sg_stream s);

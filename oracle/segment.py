@@ -83,8 +83,10 @@ class SegOracle:
             E = feats.shape[-1]
             src = feats.permute(0, 2, 1).reshape(1, E, gh, gw)
             up = jbu_oracle.jbu_forward(self.jbu_weights, src, img)
-            feats = up.reshape(1, E, H * Wd).permute(0, 2, 1)
-            gh, gw = H, Wd
+            # P=16: 16g == S, the reference's view(1, C, image_w*image_h).  P=14 (the reference cannot run it) uses the
+            # build's documented definition -- JBU to 16g, logits there, bilinear resize to S below ("parity unpinned").
+            gh, gw = up.shape[-2:]
+            feats = up.reshape(1, E, gh * gw).permute(0, 2, 1)
         feats = feats / feats.norm(dim=-1, keepdim=True)
         logits = feats @ self.text.T
         if self.cls_token_lambda != 0 and cls_logits is not None:

@@ -78,3 +78,94 @@ def test_tile_windows_match_reference_rule():
     assert len(tile_windows(512, 512, (112, 112), (224, 224))) == 16
     assert len(tile_windows(1024, 1024, (256, 256), (512, 512))) == 9
     assert tile_windows(100, 90, (112, 112), (224, 224)) == [(0, 100, 0, 90)]
+
+
+# ---- cross-tile fusion under tile sharding: strip exchange -------------------------------------------------
+class TorchCrossTileSteps:
+    """CPU stand-in for ops.CrossTileSteps (same pack / fuse / apply contract), built on the oracle's fuse functions."""
+
+    def __init__(self, gh, gw, C, bw, mode, strength, wg):
+        self.gh, self.gw, self.C, self.bw, self.mode, self.strength, self.wg = gh, gw, C, bw, mode, strength, wg
+
+    def strip_len(self, which):
+        return self.gh * self.bw if which == 0 else self.bw * self.gw
+
+    def pack(self, tokens, tile0, which, left_result=None):
+        g = tokens.reshape(-1, self.gh, self.gw, self.C).clone()
+        if which == 0:
+            return g[:, :, -self.bw:].reshape(g.shape[0], -1, self.C)
+        if left_result is not None:
+            for i in range(g.shape[0]):
+                if (tile0 + i) % self.wg > 0:
+                    g[i, :, :self.bw] = left_result[i].reshape(self.gh, self.bw, self.C)
+        return g[:, -self.bw:].reshape(g.shape[0], -1, self.C)
+
+    def fuse(self, tokens, tile0, nbr_strips, which):
+        from oracle import refine as OR
+        g = tokens.reshape(-1, self.gh, self.gw, self.C)
+        out = torch.zeros(g.shape[0], self.strip_len(which), self.C)
+        f = (lambda c, n: OR.fuse_attention(c, n, self.strength)) if self.mode == "attention" else (lambda c, n: OR.fuse_weighted(c, n, self.strength))
+        for i in range(g.shape[0]):
+            t = tile0 + i
+            hi, wi = divmod(t, self.wg)
+            if which == 0 and wi > 0:
+                out[i] = f(g[i, :, :self.bw].reshape(1, -1, self.C), nbr_strips[t - 1][None])[0]
+            if which == 1 and hi > 0:
+                out[i] = f(g[i, :self.bw].reshape(1, -1, self.C), nbr_strips[t - self.wg][None])[0]
+        return out
+
+    def apply(self, tokens, tile0, left_result, top_result):
+        g = tokens.reshape(-1, self.gh, self.gw, self.C).clone()
+        for i in range(g.shape[0]):
+            hi, wi = divmod(tile0 + i, self.wg)
+            if hi > 0:
+                g[i, :self.bw] = top_result[i].reshape(self.bw, self.gw, self.C)
+            if wi > 0:                                              # the left result wins the corner
+                g[i, :, :self.bw] = left_result[i].reshape(self.gh, self.bw, self.C)
+        return g.reshape(tokens.shape)
+
+
+def _ctf_case(grid):
+    (hg, wg), gp, C = grid, 7, 12
+    tok = torch.from_numpy(__import__("numpy").random.default_rng(5).standard_normal((hg * wg, gp * gp, C)).astype("float32"))
+    return hg, wg, gp, C, tok
+
+
+def _ctf_worker(rank, world, port, mode, grid, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clip_decontamination_amd.pipeline import sharded_cross_tile_fusion, gather_blocks
+        hg, wg, gp, C, tok = _ctf_case(grid)
+        T = hg * wg
+        lo, hi = partition(T, world, rank)
+        steps = TorchCrossTileSteps(gp, gp, C, 2, mode, 0.5, wg)
+        mine = sharded_cross_tile_fusion(tok[lo:hi].clone(), steps, T, world, rank)
+        full = gather_blocks(mine, T, world, rank)
+        q.put((rank, full))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,grid", [(2, "weighted", (3, 4)), (3, "attention", (3, 4)), (5, "weighted", (3, 4)),
+                                             (3, "weighted", (1, 2))])      # last: more ranks than tiles, rank 2 owns nothing
+def test_sharded_cross_tile_fusion_equals_sequential_reference_semantics(world, mode, grid):
+    """Partitioned tiles + two strip all-gathers == the reference module fed tile by tile in raster order
+    (oracle CrossTileFusionOracle, pinned to cross_tile_fusion.py by tests/golden/refine.npz)."""
+    from oracle import refine as OR
+    hg, wg, gp, C, tok = _ctf_case(grid)
+    o = OR.CrossTileFusionOracle(mode, 2, 0.5)
+    ref = torch.stack([o(tok[t:t + 1].clone(), t // wg, t % wg, gp, gp)[0] for t in range(hg * wg)], 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ctf_worker, args=(r, world, port, mode, grid, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, full in res:
+        assert full.shape == ref.shape
+        assert (full - ref).abs().max().item() < 1e-5, f"rank {rank}"

@@ -7,7 +7,7 @@ from clip_decontamination_amd import _lib
 
 lib = _lib.load()
 dev = "cuda:0"
-M = 32 * 1370
+M = int(os.environ.get("GEMM_TILES", "32")) * 1370
 SHAPES = [("qkv", M, 3072, 1024, 0, 1), ("out", M, 1024, 1024, 0, 0), ("fc", M, 4096, 1024, 1, 1), ("proj", M, 1024, 4096, 0, 0)]
 CONFIGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6".split(","))]
 ROUNDS, ITERS = 5, 10
