@@ -17,6 +17,7 @@ namespace sg {
 
 constexpr int QB = 128;        // queries per workgroup
 constexpr int KT = 64;         // keys per LDS tile
+constexpr float RESCALE_TAU = 8.0f;   // log2 units: probabilities may reach 2^8 before the running maximum is raised
 
 typedef __attribute__((ext_vector_type(4))) short short4_;
 typedef __attribute__((address_space(3))) short4_* lds_s4_ptr;
@@ -69,8 +70,15 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
   bf16_t* sbuf = reinterpret_cast<bf16_t*>(smem);                       // [2][BUF]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q_glob = blockIdx.x * QB + wave * 32 + c;
+  // XCD-aware order: workgroup w runs on XCD w % 8 (dispatch round-robin; used for speed only).  All query blocks of one
+  // (image, head) pair are queued back to back on ONE XCD, so its K / V (350 kB at N=1370) are fetched into that XCD's L2 once
+  // instead of once per query block through the fabric (rocprofv3 FETCH_SIZE: 6.1 GB -> see profiles/).
+  const int nq = (a.N + QB - 1) / QB;
+  const int xw = blockIdx.x & 7, jw = blockIdx.x >> 3;
+  const int grp = (jw / nq) * 8 + xw;
+  if (grp >= a.H * a.B) return;
+  const int b = grp / a.H, hd = grp % a.H;
+  const int q_glob = (jw % nq) * QB + wave * 32 + c;
   const int q_ld = q_glob < a.N ? q_glob : a.N - 1;
   const int n = a.N - 1;
   const float scale = a.scale_per_image ? a.scale_per_image[b] : a.scale;      // > 0
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
       for (int r = 0; r < 16; ++r) o_tot[t][r] = 0.f;
   }
   f32x16 o_acc[C::DVT];
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;                     // m_run: the (stale) maximum the exponentials are taken against
 
   for (int sidx = 0; sidx < n_streams; ++sidx) {
     const bf16_t* kptr[TS];
@@ -216,32 +224,36 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
         mloc *= c2;                                        // c2 > 0: max commutes with the scaling
       }
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      // Lazy online softmax: the exponentials use a STALE maximum m_run that is only raised (and the accumulators rescaled) when some
+      // row's maximum has outgrown it by more than 2^RESCALE_TAU -- probabilities stay <= 2^TAU, exact in the final O / l ratio.
+      // The branch is wave-uniform and, after the first tiles, almost never taken (the 32 accumulator multiplies per tile go away).
+      if (__any(mloc > m_run + RESCALE_TAU)) {
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = m_new == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+        for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+        l_run *= alpha;
+        m_run = m_new;
+      }
+      const float m_sub = m_run == -INFINITY ? 0.f : m_run;   // a row with nothing unmasked yet: exp2(-inf - 0) = 0, never inf - inf
       float lsum = 0.f;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const float x = GENERIC ? sc[i] - m_new : fmaf(sacc[i >> 4][i & 15], c2, -m_new);
+        const float x = GENERIC ? sc[i] - m_sub : fmaf(sacc[i >> 4][i & 15], c2, -m_sub);
         sc[i] = __builtin_amdgcn_exp2f(x);
         lsum += sc[i];
       }
       lsum += __shfl_xor(lsum, 32, 64);
-      l_run = l_run * alpha + lsum;
-      const bool grew = m_new > m_run;
-      m_run = m_new;
+      l_run += lsum;
+      // P (bf16) is already the B operand: element j of k-step s2 of sub-block sub = sc[16 sub + 8 s2 + j]
+      bf16x8 pf[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
       if (do_pv) {
-        if (__any(grew)) {                                 // wave-uniform: skip the rescale when no row maximum moved
-#pragma unroll
-          for (int t = 0; t < C::DVT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
-        }
-        // P (bf16) is already the B operand: element j of k-step s2 of sub-block sub = sc[16 sub + 8 s2 + j]
-        bf16x8 pf[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
 #pragma unroll
         for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
@@ -296,7 +308,9 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   auto kern = generic ? (multi ? attn_kernel<DH, TS, true, true> : attn_kernel<DH, TS, true, false>)
                       : (multi ? attn_kernel<DH, TS, false, true> : attn_kernel<DH, TS, false, false>);
   if (lds > 64 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid((unsigned)cdiv(a.N, QB), (unsigned)a.H, (unsigned)a.B);
+  const int64_t n_grp8 = cdiv((int64_t)a.H * a.B, 8);
+  SG_REQUIRE(n_grp8 * 8 * cdiv(a.N, QB) < (1ll << 31), "attention: grid too large");
+  dim3 grid((unsigned)(n_grp8 * 8 * cdiv(a.N, QB)));
   // algorithmic FLOPs: 2*N*N*dh per (term score) + 2*N*N*dh per stream PV, per (image, head)
   const int streams = a.sum_scores ? 1 : a.n_terms;
   const double fl = (double)a.B * a.H * 2.0 * a.N * (double)a.N * DH * (a.n_terms + (a.ctx ? streams : 0));

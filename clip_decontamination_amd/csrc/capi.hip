@@ -22,9 +22,9 @@ struct ProfState {
   bool on = false;
   int cap = 0;
   std::vector<hipEvent_t> start[PROF_NCAT], stop[PROF_NCAT];
-  int used[PROF_NCAT] = {0, 0, 0};
-  double work[PROF_NCAT] = {0, 0, 0};
-  int64_t dropped[PROF_NCAT] = {0, 0, 0};
+  int used[PROF_NCAT] = {};
+  double work[PROF_NCAT] = {};
+  int64_t dropped[PROF_NCAT] = {};
 };
 static ProfState g_prof;
 bool prof_on() { return g_prof.on; }
@@ -339,7 +339,8 @@ extern "C" int sg_set_gemm_config(int cfg) {
   return SG_OK;
 }
 extern "C" int sg_profile_disable(void) { g_prof.on = false; return SG_OK; }
-// category: 0 bf16 GEMM, 1 fused attention, 2 f32 GEMM.  Call after the stream has been synchronised.
+// category: 0 bf16 GEMM (non-persistent tile variants), 1 fused attention, 2 f32 GEMM, 3 the persistent bf16 GEMM.  Call after the stream
+// has been synchronised.
 extern "C" int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped) {
   SG_REQUIRE(category >= 0 && category < PROF_NCAT && total_ms && total_flops && launches, "sg_profile_read: bad argument");
   double ms = 0;

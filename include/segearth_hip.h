@@ -107,7 +107,8 @@ int sg_version(void);
 
 /* ---- live kernel timing (measurement only; used by bench.py's roofline) -------------------------
  * HIP events bracket every launch of a kernel family on the stream it is launched on.
- * category: 0 = bf16 MFMA GEMM, 1 = fused attention, 2 = f32 MFMA GEMM.  Read after synchronising. */
+ * category: 0 = bf16 MFMA GEMM (small-shape tile variants), 1 = fused attention, 2 = f32 MFMA GEMM,
+ *           3 = the persistent bf16 GEMM (every large ViT linear; the kernel bench.py's roofline prices).  Read after synchronising. */
 int sg_profile_enable(int capacity);
 int sg_profile_disable(void);
 int sg_set_gemm_config(int cfg);   /* tuning hook: bf16 GEMM tile variant, -1 = automatic */
