@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsegearth_hip.so")
 ARCH = "gfx950"
 SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "rowops.hip", "patchify.hip", "refine.hip",
-           "head.hip", "jbu.hip"]
+           "head.hip", "jbu.hip", "ctd.hip"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 

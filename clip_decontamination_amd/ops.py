@@ -224,6 +224,34 @@ def cross_tile_fusion(tokens, hg: int, wg: int, gh: int, gw: int, boundary_width
     return tokens
 
 
+def global_debias(tokens, cls, factor: float):
+    """tokens - cls_hat * (cos(tokens, cls_hat) * factor)  (segmentor.py:322-336); cls is normalised inside."""
+    lib = _lib.load()
+    tokens, cls = _f32(tokens), _f32(cls)
+    _require_gpu(tokens, cls)
+    B, n, E = tokens.shape
+    out = torch.empty_like(tokens)
+    check(lib.sg_global_debias(ptr(tokens), ptr(cls), B, n, E, float(factor), ptr(out), stream_ptr()), "sg_global_debias")
+    return out
+
+
+def ctd_debias(tokens, cls, eps: float = 1.1, min_samples: int = 11, factor: float = -1.5, want_labels: bool = True, normalize_cls: bool = False):
+    """Cluster-Then-Debias (segmentor.py:339-365): tokens [B,n,C], CLS features [B,C] (unit unless ``normalize_cls``) ->
+    (debiased copy, labels int32 [B,n])."""
+    lib = _lib.load()
+    tokens = _f32(tokens).clone()
+    cls = _f32(cls)
+    _require_gpu(tokens, cls)
+    B, n, Cc = tokens.shape
+    labels = torch.empty(B, n, dtype=torch.int32, device=tokens.device) if want_labels else None
+    need = lib.sg_ctd_scratch_bytes(B, n, Cc)
+    buf = scratch(need, tokens.device)
+    sp, sn = _aligned(buf)
+    check(lib.sg_ctd_debias(ptr(tokens), ptr(cls), B, n, Cc, float(eps), int(min_samples), float(factor), int(normalize_cls), ptr(labels), sp, sn,
+                            stream_ptr()), "sg_ctd_debias")
+    return tokens, labels
+
+
 class CrossTileSteps:
     """The three device steps of the sharded cross-tile fusion (sg_cross_tile_pack / _fuse / _apply) for a rank holding tiles
     [tile0, tile0+n_local) of a scene whose tile grid is ``wg`` wide.  ``pipeline.sharded_cross_tile_fusion`` drives them and

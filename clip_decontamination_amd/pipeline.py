@@ -78,7 +78,7 @@ class SegPipeline:
     def __init__(self, net: HipCLIP, text: torch.Tensor, query_idx: torch.Tensor, model_type: str = "SegEarth",
                  ignore_residual: bool = True, cls_token_lambda: float = 0.0, global_debias_factor: float = 0.0,
                  logit_scale: float = 50.0, prob_thd: float = 0.0, bg_idx: int = 0, apply_similarity_enhancement: bool = False,
-                 upsampler=None, tiles_per_launch: int = 32, cross_tile_fusion: Optional[dict] = None):
+                 upsampler=None, tiles_per_launch: int = 32, cross_tile_fusion: Optional[dict] = None, apply_ctd: bool = False):
         self.net = net
         self.visual = net.visual
         self.device = self.visual.device
@@ -96,6 +96,17 @@ class SegPipeline:
         self.tiles_per_launch = int(tiles_per_launch)
         # opt-in: the reference ships CrossTileFusion but never calls it; kwargs of its constructor
         self.cross_tile_fusion = cross_tile_fusion
+        self.apply_ctd = bool(apply_ctd)                 # Cluster-Then-Debias (segmentor.py:339-365), SegmentorEx only
+
+    def _pre_head(self, tok, cls):
+        """Global debias (+ CTD) when they cannot stay fused in the logits kernel: returns (tokens, remaining debias factor)."""
+        f = self.global_debias_factor if cls is not None else 0.0
+        if not getattr(self, "apply_ctd", False) or cls is None:
+            return tok, f
+        if f != 0:                                            # reference order: global debias, then cluster on the debiased features
+            tok = ops.global_debias(tok, cls, f)
+        tok, _ = ops.ctd_debias(tok, cls, eps=1.1, min_samples=11, factor=-1.5, want_labels=False, normalize_cls=True)
+        return tok, 0.0
 
     # -- per-tile logits -----------------------------------------------------------------------------------
     def tile_logits(self, scene: torch.Tensor, windows: Sequence[Tuple[int, int, int, int]], tile_hw: Tuple[int, int],
@@ -124,20 +135,20 @@ class SegPipeline:
             cls = None if cls_all[0] is None else torch.cat(cls_all, 0)
             if self.upsampler is not None:
                 raise NotImplementedError("cross-tile fusion together with the JBU upsampler is not wired")
-            lg = ops.cosine_logits(tok, cls, self.text, self.global_debias_factor if cls is not None else 0.0,
-                                   self.cls_token_lambda if cls is not None else 0.0)
+            tok, f = self._pre_head(tok, cls)
+            lg = ops.cosine_logits(tok, cls, self.text, f, self.cls_token_lambda if cls is not None else 0.0)
             return lg.reshape(win.shape[0], self.num_queries, gh, gw)
         for i in range(0, win.shape[0], self.tiles_per_launch):
             w = win[i:i + self.tiles_per_launch]
             si = None if scene_index is None else scene_index[i:i + self.tiles_per_launch]
             cls, tok = v.forward_tiles(scene, w, tile_hw, opts, si)
+            tok, f = self._pre_head(tok, cls)
             if self.upsampler is not None:
                 outs.append(self.upsampler.logits(tok, cls, scene, w, tile_hw, (l, t), (gh, gw), self.text,
-                                                  self.global_debias_factor, self.cls_token_lambda, si,
+                                                  f, self.cls_token_lambda, si,
                                                   padded_hw=(th + t + b, tw + l + r)))
             else:
-                lg = ops.cosine_logits(tok, cls, self.text, self.global_debias_factor if cls is not None else 0.0,
-                                       self.cls_token_lambda if cls is not None else 0.0)
+                lg = ops.cosine_logits(tok, cls, self.text, f, self.cls_token_lambda if cls is not None else 0.0)
                 outs.append(lg.reshape(w.shape[0], self.num_queries, gh, gw))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
@@ -210,8 +221,8 @@ class SegPipeline:
         tok = sharded_cross_tile_fusion(tok, steps, T, world, rank, group)
         if n_real == 0:
             return tok.new_zeros((0, self.num_queries, gh, gw))
-        lg = ops.cosine_logits(tok, cls, self.text, self.global_debias_factor if cls is not None else 0.0,
-                               self.cls_token_lambda if cls is not None else 0.0)
+        tok, f = self._pre_head(tok, cls)
+        lg = ops.cosine_logits(tok, cls, self.text, f, self.cls_token_lambda if cls is not None else 0.0)
         return lg.reshape(n_real, self.num_queries, gh, gw)
 
     # -- reference forward_feature (whole image / explicit logit size) ------------------------------------------

@@ -218,7 +218,7 @@ class _HipSegmentorBase(_Base):
                            global_debias_factor=self.global_debias_factor, logit_scale=self.logit_scale, prob_thd=self.prob_thd,
                            bg_idx=self.bg_idx, apply_similarity_enhancement=getattr(self, "apply_similarity_enhancement", False),
                            upsampler=self.upsampler, tiles_per_launch=self._tiles_per_launch,
-                           cross_tile_fusion=getattr(self, "cross_tile_fusion_cfg", None))
+                           cross_tile_fusion=getattr(self, "cross_tile_fusion_cfg", None), apply_ctd=getattr(self, "apply_ctd", False))
 
     def forward_feature(self, img, logit_size=None, tile_h_idx=None, tile_w_idx=None):
         """Reference segmentor.py:286-392.  img [B,3,H,W] -> logits [B,Q,h,w]."""
@@ -301,8 +301,6 @@ class SegmentorEx(_HipSegmentorBase):
         if model_type == "GEM":
             raise ValueError("model_type='GEM' crashes in the reference SegmentorEx (it unpacks (cls, feats), SURVEY.md R5); "
                              "use segearth_segmentor.Segmentor with cls_token_lambda=0")
-        if _to_bool(apply_ctd):
-            raise NotImplementedError("apply_ctd (DBSCAN cluster-then-debias) is CPU clustering outside the HIP hot path (SURVEY.md §8f rank 4)")
         if _to_bool(apply_layer_fusion):
             raise NotImplementedError("apply_layer_fusion is internally inconsistent in the reference (SURVEY.md R9) and is not built")
         visual = self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
@@ -310,7 +308,7 @@ class SegmentorEx(_HipSegmentorBase):
                              checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer)
         # opt-in extra: kwargs of the reference's CrossTileFusion (cross_tile_fusion.py:24-60), which the reference never calls (R2)
         self.cross_tile_fusion_cfg = cross_tile_fusion_cfg
-        self.apply_ctd = False
+        self.apply_ctd = _to_bool(apply_ctd)                                # segmentor.py:184-194, 339-365: DBSCAN + cluster debias, on the device here
         self.apply_layer_fusion, self.layer_fusion_lambda, self.layer_fusion_threshold = False, layer_fusion_lambda, layer_fusion_threshold
         self.apply_similarity_enhancement = _to_bool(apply_similarity_enhancement)
         if self.apply_similarity_enhancement:                               # segmentor.py:196-220

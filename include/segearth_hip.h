@@ -211,6 +211,16 @@ int sg_op_attention(const float* qkv, int B, int N, int D, int H, int variant, c
  *   input [B,C,h+d-1,w+d-1], filters [B,h,w,d,d] -> out [B,C,h,w], all f32. */
 int sg_adaptive_conv(const float* input, const float* filters, int B, int C, int h, int w, int d, float* out, sg_stream s);
 
+/* ---- Cluster-Then-Debias (reference CTD.py as segmentor.py:339-365 drives it) --------------------
+ * sg_ctd_debias replaces, for every tile of a launch at once,
+ *     _, labels = cluster_patch_tokens_dbscan(feats, grid_hw, {'metric': 'euclidean', 'eps': eps, 'min_samples': m})   CTD.py:147-296
+ *     feats     = adaptive_debiasing(items=feats, labels=labels, bias=cls, factor=factor)                              CTD.py:299-366
+ * (scikit-learn DBSCAN on the CPU in the reference).  tokens [B,n,C] f32 in/out, cls [B,C] = the CLS features (unit, or raw with
+ * normalize_cls = 1: segmentor.py:310 normalises them first), labels_out int32 [B,n] (-1 = noise) or NULL.  n > 8192 leaves the tokens unchanged, as the reference's max_points does. */
+size_t sg_ctd_scratch_bytes(int B, int n, int C);
+int sg_ctd_debias(float* tokens, const float* cls, int B, int n, int C, double eps, int min_samples, float factor, int normalize_cls,
+                  int32_t* labels_out, void* scratch, size_t scratch_bytes, sg_stream s);
+
 /* ---- CLIP text tower (init-time producer of query_features) -------------------------------------
  * sg_text_encode replaces CLIP.encode_text(tokens) (open_clip/model.py:288-306): token + positional embedding, causal
  * residual blocks, ln_final, EOT pooling (argmax of the ids), @ text_projection.  Tensor names = the text part of the CLIP

@@ -3,7 +3,7 @@
 deterministic synthetic weights and inputs.  Runs only in the build container; the fixtures are
 data (inputs' seeds + expected outputs), never reference source.
 
-    python -m oracle.gen_golden [--only tiny|refine|jbu|segment|text|real]
+    python -m oracle.gen_golden [--only tiny|refine|jbu|segment|text|ctd|real]
 
 Every fixture is cross-checked here against the build's own CPU restatement (oracle/*.py) so a
 drift between the two fails at mint time, and again in tests/test_oracle_vs_golden.py.
@@ -107,7 +107,7 @@ def ref_segmentor(cls_name, net, cfg, text, query_idx, **kw):
     s.prob_thd = kw.get("prob_thd", 0.0)
     s.slide_stride = kw.get("slide_stride", 112)
     s.slide_crop = kw.get("slide_crop", 224)
-    s.apply_ctd = False
+    s.apply_ctd = kw.get("apply_ctd", False)
     s.apply_layer_fusion = False
     s.layer_fusion_lambda = 0.5
     s.layer_fusion_threshold = 0.7
@@ -324,6 +324,9 @@ def gen_segment():
                                        prob_thd=0.0, slide_crop=36, slide_stride=20), (60, 75)),
         "se_plain": ("Segmentor", dict(model_type="SegEarth", cls_token_lambda=-0.3, slide_crop=32, slide_stride=16), (48, 64)),
         "ex_small": ("SegmentorEx", dict(model_type="ClearCLIP", slide_crop=32, slide_stride=16), (24, 40)),   # image < crop
+        # Cluster-Then-Debias (sklearn DBSCAN inside the reference), 8x8 patch grid per tile
+        "ex_ctd": ("SegmentorEx", dict(model_type="SegEarth", global_debias_factor=0.2, apply_ctd=True, prob_thd=0.1, bg_idx=5,
+                                       slide_crop=64, slide_stride=32), (96, 128)),
     }
     with torch.no_grad():
         for name, (cls_name, kw, (H, Wd)) in cases.items():
@@ -337,7 +340,7 @@ def gen_segment():
                        global_debias_factor=kw.get("global_debias_factor", 0.0),
                        similarity_cfg=kw.get("similarity_cfg"), outlier_cfg=kw.get("outlier_cfg"),
                        prob_thd=kw.get("prob_thd", 0.0), bg_idx=kw.get("bg_idx", 0),
-                       slide_crop=kw["slide_crop"], slide_stride=kw["slide_stride"])
+                       slide_crop=kw["slide_crop"], slide_stride=kw["slide_stride"], apply_ctd=kw.get("apply_ctd", False))
             o = OS.SegOracle(cfg, w, torch.from_numpy(text), torch.tensor(POTSDAM_QIDX), **okw)
             ol = o.forward_slide(img)
             close(ol, logits, 3e-5, f"{name} slide logits")
@@ -346,8 +349,9 @@ def gen_segment():
             print(f"    {name}: argmax agreement {agree:.4f}")
             assert agree == 1.0
             # one-tile forward_feature with an explicit logit_size (slide_crop == 0 path)
-            ff = s.forward_feature(img[:, :, :32, :32], (40, 44))
-            close(o.forward_feature(img[:, :, :32, :32], (40, 44)), ff, 3e-5, f"{name} forward_feature")
+            fc = kw["slide_crop"] if kw.get("apply_ctd") else 32
+            ff = s.forward_feature(img[:, :, :fc, :fc], (40, 44))
+            close(o.forward_feature(img[:, :, :fc, :fc], (40, 44)), ff, 3e-5, f"{name} forward_feature")
             out.update({f"{name}.img": img, f"{name}.logits": logits, f"{name}.pred": pred, f"{name}.ff": ff})
         # GEM through segearth_segmentor.Segmentor (the only class where GEM runs, R5)
         gcfg = Wt.vit_config("tiny-gem")
@@ -392,6 +396,33 @@ def gen_text():
         save(f"text_{name}", tokens=ids, features=ref.numpy(), features_normalized=refn.numpy())
 
 
+def gen_ctd():
+    """ctd.npz: the reference's Cluster-Then-Debias step exactly as segmentor.py:339-365 calls it (sklearn DBSCAN inside)."""
+    from oracle import ctd as OC
+    CTD = R.ref("CTD")
+    out = {}
+    for tag, (n_side, C, spread, nc, seed) in {"a": (12, 32, 0.3, 4, 4), "b": (20, 48, 0.35, 7, 10)}.items():
+        n = n_side * n_side
+        x = torch.from_numpy(OC.make_clustered_tokens(2, n, C, seed=seed, spread=spread, n_centers=nc))
+        g = np.random.default_rng(100 + seed)
+        cls = torch.from_numpy(g.standard_normal((2, C)).astype(np.float32))
+        cls = cls / cls.norm(dim=-1, keepdim=True)
+        feats = x.clone()
+        _, labels = CTD.cluster_patch_tokens_dbscan(feats, grid_hw=(n_side, n_side),
+                                                   cfg_dict={"max_points": 8192, "metric": "euclidean", "eps": 1.1, "min_samples": 11})
+        ref = CTD.adaptive_debiasing(items=feats.clone(), labels=labels, bias=cls, factor=-1.5)
+        mine, mlab = OC.ctd_debias(x, cls)
+        assert torch.equal(mlab, labels), "DBSCAN restatement differs from the reference"
+        close(mine, ref, 1e-6, f"ctd {tag}")
+        for b in range(2):                                       # the fixture must not hinge on a rounding-level tie
+            _, d2 = OC.neighbour_matrix(OC.ctd_points(x)[b].numpy(), 1.1)
+            assert np.abs(d2 - 1.21).min() > 1e-4
+        print(f"    ctd {tag}: clusters per tile {[int(l.max()) + 1 for l in labels]}, noise {[int((l < 0).sum()) for l in labels]}")
+        out.update({f"{tag}.tokens": x.numpy(), f"{tag}.cls": cls.numpy(), f"{tag}.labels": labels.numpy().astype(np.int32),
+                    f"{tag}.out": ref.numpy()})
+    save("ctd", **out)
+
+
 def gen_real():
     """Real-size towers: patch-grid logits, CLS logits and argmax maps on seeded tiles
     (inputs are regenerated from the seed on the GPU box; only outputs are stored)."""
@@ -434,7 +465,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    steps = {"tiny": gen_tiny, "refine": gen_refine, "jbu": gen_jbu, "segment": gen_segment, "text": gen_text, "real": gen_real}
+    steps = {"tiny": gen_tiny, "refine": gen_refine, "jbu": gen_jbu, "segment": gen_segment, "text": gen_text, "ctd": gen_ctd, "real": gen_real}
     for k, fn in steps.items():
         if not a.only or a.only == k:
             fn()

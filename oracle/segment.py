@@ -53,6 +53,7 @@ class SegOracle:
     slide_crop: int = 224
     gem_depth: int = 7
     segearth_variant: bool = False          # segearth_segmentor.Segmentor semantics (no debias/refiners)
+    apply_ctd: bool = False                 # Cluster-Then-Debias (segmentor.py:339-365)
 
     @property
     def num_queries(self):
@@ -79,6 +80,9 @@ class SegOracle:
             cn = cls / cls.norm(dim=-1, keepdim=True)
             sim = (fn * cn.unsqueeze(1)).sum(-1)
             feats = feats - cls.unsqueeze(1) * (sim.unsqueeze(-1) * self.global_debias_factor)
+        if self.apply_ctd and cls is not None:                                 # :339-365
+            from oracle import ctd as ctd_oracle
+            feats, _ = ctd_oracle.ctd_debias(feats, cls, eps=1.1, min_samples=11, factor=-1.5)
         if self.jbu_weights is not None:                                       # :368-372 (B=1)
             E = feats.shape[-1]
             src = feats.permute(0, 2, 1).reshape(1, E, gh, gw)

@@ -341,3 +341,52 @@ def test_cross_tile_fusion_larger_grid_vs_oracle(ops):
         ref = torch.stack([o(tok[t:t + 1].clone(), t // wg, t % wg, gp, gp)[0] for t in range(hg * wg)], 0)
         out = ops.cross_tile_fusion(tok.to(DEV), hg, wg, gp, gp, 2, mode, 0.5)
         assert (out.cpu() - ref).abs().max().item() < 3e-5
+
+
+# ---- Cluster-Then-Debias (CTD.py via segmentor.py:339-365) ---------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ctd_matches_reference_fixture(ops, golden, tag):
+    """Fixture = the reference's cluster_patch_tokens_dbscan (scikit-learn DBSCAN) + adaptive_debiasing.  Labels are integer
+    work: exact.  The fixture holds no pair within 1e-4 of eps^2 (checked when it was minted)."""
+    g = golden("ctd")
+    out, labels = ops.ctd_debias(torch.from_numpy(g[f"{tag}.tokens"]).to(DEV), torch.from_numpy(g[f"{tag}.cls"]).to(DEV))
+    assert np.array_equal(labels.cpu().numpy(), g[f"{tag}.labels"])
+    assert (out.cpu() - torch.from_numpy(g[f"{tag}.out"])).abs().max().item() < 1e-5
+
+
+def test_ctd_real_grid_vs_oracle(ops):
+    """The L/14 tile shape (37 x 37 tokens, 768 channels), 3 tiles, raw (un-normalised) CLS features."""
+    from oracle import ctd as OC
+    x = torch.from_numpy(OC.make_clustered_tokens(3, 1369, 768, seed=2, spread=0.5, n_centers=9))
+    cls = torch.from_numpy(np.random.default_rng(9).standard_normal((3, 768)).astype(np.float32))
+    out, labels = ops.ctd_debias(x.to(DEV), cls.to(DEV), normalize_cls=True)
+    ref, rlab = OC.ctd_debias(x, cls / cls.norm(dim=-1, keepdim=True))
+    pts = OC.ctd_points(x)
+    margin = min(np.abs(OC.neighbour_matrix(pts[b].numpy(), 1.1)[1] - 1.21).min() for b in range(3))
+    same = (labels.cpu().long() == rlab).float().mean().item()
+    print(f"[ctd 37x37x768] clusters {[int(l.max()) + 1 for l in rlab]}, noise {[int((l < 0).sum()) for l in rlab]}, "
+          f"closest pair to the radius {margin:.2e}, label agreement {same:.6f}")
+    if margin > 1e-6:                                        # no pair sits on the radius to within the f32 rounding of the points
+        assert same == 1.0
+        assert (out.cpu() - ref).abs().max().item() < 1e-4
+    else:
+        assert same > 0.99
+
+
+def test_ctd_edge_cases(ops):
+    g = torch.Generator().manual_seed(0)
+    # all noise (isotropic points in 64-D never have 11 neighbours within cos > 0.395): tokens unchanged, labels -1
+    x = torch.randn(2, 50, 64, generator=g)
+    cls = torch.nn.functional.normalize(torch.randn(2, 64, generator=g), dim=-1)
+    out, labels = ops.ctd_debias(x.to(DEV), cls.to(DEV))
+    assert (labels == -1).all() and torch.equal(out.cpu(), x)
+    # one cluster holding every token (identical directions)
+    y = torch.randn(1, 1, 64, generator=g).expand(1, 40, 64) * torch.linspace(0.5, 2.0, 40).view(1, 40, 1)
+    out, labels = ops.ctd_debias(y.contiguous().to(DEV), cls[:1].to(DEV))
+    assert (labels == 0).all()
+    from oracle import ctd as OC
+    ref, _ = OC.ctd_debias(y.contiguous(), cls[:1])
+    assert (out.cpu() - ref).abs().max().item() < 1e-5
+    # fewer points than min_samples
+    out, labels = ops.ctd_debias(x[:, :5].contiguous().to(DEV), cls.to(DEV))
+    assert (labels == -1).all()

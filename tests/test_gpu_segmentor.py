@@ -19,6 +19,9 @@ CASES = {
     "ex_pad": ("SegmentorEx", dict(model_type="SegEarth", global_debias_factor=0.2, cls_token_lambda=-0.3, slide_crop=36, slide_stride=20)),
     "se_plain": ("Segmentor", dict(model_type="SegEarth", cls_token_lambda=-0.3, slide_crop=32, slide_stride=16, apply_sim_feat_up=False)),
     "ex_small": ("SegmentorEx", dict(model_type="ClearCLIP", slide_crop=32, slide_stride=16)),
+    # Cluster-Then-Debias: the reference runs scikit-learn DBSCAN on the CPU per tile (segmentor.py:339-365)
+    "ex_ctd": ("SegmentorEx", dict(model_type="SegEarth", global_debias_factor=0.2, apply_ctd=True, prob_thd=0.1, bg_idx=5,
+                                   slide_crop=64, slide_stride=32)),
 }
 
 
@@ -40,7 +43,8 @@ def test_slide_feature_postprocess_match_reference(golden, name):
     assert (logits.cpu() - torch.from_numpy(g[f"{name}.logits"])).abs().max().item() < 1e-3
     pred = seg.postprocess_result(logits, None)
     assert torch.equal(pred.cpu(), torch.from_numpy(g[f"{name}.pred"]))
-    ff = seg.forward_feature(img[:, :, :32, :32], (40, 44))
+    fc = 64 if name == "ex_ctd" else 32
+    ff = seg.forward_feature(img[:, :, :fc, :fc], (40, 44))
     assert (ff.cpu() - torch.from_numpy(g[f"{name}.ff"])).abs().max().item() < 1e-3
     # predict(): same path behind the mmseg entry point (data_samples=None returns the label map)
     pred2 = seg.predict(img, None)

@@ -205,3 +205,14 @@ def test_text_tower(golden, name):
         assert maxdiff(OT.encode_text(w, tc, g["tokens"]), g["features"]) < TOL
         assert maxdiff(OT.encode_text(w, tc, g["tokens"], normalize=True), g["features_normalized"]) < TOL
     assert (g["tokens"] == Wt.make_token_ids(tc, g["tokens"].shape[0]))[0].all()      # ids regenerate from the seed
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_cluster_then_debias(golden, tag):
+    """oracle/ctd.py vs the reference's CTD step (sklearn DBSCAN + adaptive_debiasing, segmentor.py:339-365)."""
+    from oracle import ctd as OC
+    g = golden("ctd")
+    out, labels = OC.ctd_debias(t(g[f"{tag}.tokens"]), t(g[f"{tag}.cls"]))
+    assert np.array_equal(labels.numpy(), g[f"{tag}.labels"])
+    assert maxdiff(out, g[f"{tag}.out"]) < 1e-5
+    assert labels.max() >= 1 and (labels < 0).any()          # several clusters and some noise: the case is not degenerate
