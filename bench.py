@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="bf16 = the headline configuration; fp8 = ordinary-block linears on fp8 MFMA (reported separately, never the default)")
     ap.add_argument("--tile-cols", type=int, default=TILE_COLS, help="tiles per scene row")
     ap.add_argument("--tile-rows", type=int, default=TILE_ROWS_PER_RANK, help="tile rows per rank (weak scaling: the scene grows with the ranks)")
     ap.add_argument("--tiles-per-launch", type=int, default=0, help="0 = all of a rank's tiles in one launch of the tower")
@@ -199,12 +200,13 @@ def main():
         g_ms, g_fl, g_n, g_drop = prof(3)                  # gemm_bf16_persist: the dominant kernel (every large ViT linear)
         o_ms, o_fl, o_n, _ = prof(0)                       # the remaining bf16 GEMM launches (patch embed, proj, similarity map)
         a_ms, a_fl, a_n, _ = prof(1)
+        f_ms, f_fl, f_n, _ = prof(4)                       # fp8 GEMM launches (only with --precision fp8)
         achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         out = {
             "metric": "segmented Mpix/sec ViT-L/14 512-tile slide", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "ViT-L/14, 512x512x3 uint8 tiles at stride 256 (padded to 518, N=1370 tokens), "
                                    "model_type=Experimental + similarity enhancement + outlier suppression k=30 + global debias 0.2, "
                                    "8 Potsdam queries / 6 classes, slide stitch + arg-max labels",
@@ -216,6 +218,8 @@ def main():
                          "algorithmic_gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3), "events_dropped": g_drop,
                          "attention": {"kernel": "attn_kernel", "achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else 0.0,
                                        "launches": a_n, "avg_launch_us": round(a_ms * 1e3 / max(a_n, 1), 2)},
+                         "fp8_gemm": ({"kernel": "gemm_bf16_ring<256,128,...,FP8>", "achieved": round(f_fl / (f_ms * 1e-3) / 1e12, 2), "launches": f_n,
+                                       "peak": 5000.0, "share_of_step_time": round(f_ms / (dt * 1e3), 4)} if f_n else None),
                          "share_of_step_time": {"gemm_bf16_persist": round(g_ms / (dt * 1e3), 4), "other_bf16_gemm": round(o_ms / (dt * 1e3), 4),
                                                 "attention": round(a_ms / (dt * 1e3), 4)}},
         }

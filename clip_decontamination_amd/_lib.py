@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsegearth_hip.so")
 
 # enums (include/segearth_hip.h)
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_FP8 = 0, 1, 2
 MODEL_TYPES = {"vanilla": 0, "MaskCLIP": 1, "ClearCLIP": 2, "SCLIP": 3, "SegEarth": 4, "SFP": 5, "Experimental": 6,
                "NACLIP": 7, "NOnly": 8, "GAV": 9, "GEM": 10}
 IMG_F32_NCHW, IMG_U8_NHWC = 0, 1
@@ -68,6 +68,8 @@ SIGNATURES = {
     "sg_similarity_map": (I, [P, L, I, I, I, I, F, I, I, P, P, Z, P]),
     "sg_op_linear": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),
     "sg_gemm_bf16_raw": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "sg_gemm_fp8_raw": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "sg_quantize_rows_fp8": (I, [P, L, I, P, P, P]),
     "sg_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
     "sg_op_attention_scratch_bytes": (Z, [I, I, I, I, I]),
     "sg_op_attention": (I, [P, I, I, I, I, I, P, F, P, P, P, I, P, Z, P]),

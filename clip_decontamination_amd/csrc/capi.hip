@@ -55,6 +55,8 @@ struct Bump {
 
 struct LayerW {
   void *w_qkv, *w_out, *w_fc, *w_proj;                 // packed [N_out, K] in the compute dtype
+  uint8_t *w_qkv8, *w_fc8, *w_proj8;                   // SG_PREC_FP8: e4m3 copies + per-output-channel scales
+  float *s_qkv, *s_fc, *s_proj;
   float *b_qkv, *b_out, *b_fc, *b_proj, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
 };
 
@@ -67,6 +69,7 @@ struct sg_context {
   int device;
   int Kpatch, Kpad;
   bool bf16;
+  bool fp8;                                            // SG_PREC_FP8: bf16 machinery + fp8 linears in the ordinary blocks
   size_t esz;                                          // bytes per element of the compute dtype
   void* arena; size_t arena_bytes;
   std::vector<LayerW> layers;
@@ -206,6 +209,16 @@ static int linear(bool bf16, const void* A, int64_t lda, const void* W, const fl
   return gemm_f32(g, s);
 }
 
+// C = act((A8 . W8^T) * sa[m] * sw[n] + bias) (+ residual): fp8 e4m3 operands, f32 accumulate
+static int linear_fp8(const uint8_t* A8, const float* sa, int64_t lda, const uint8_t* W8, const float* sw, const float* bias,
+                      const float* residual, void* C, int64_t ldc, bool c_f32, int M, int N, int K, int act, hipStream_t s) {
+  GemmBf16Args g{};
+  g.A = (const bf16_t*)A8; g.lda = lda; g.W = (const bf16_t*)W8; g.ldw = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
+  g.C = C; g.ldc = ldc; g.c_is_bf16 = c_f32 ? 0 : 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f;
+  g.fp8 = 1; g.row_scale = sa; g.col_scale = sw;
+  return gemm_bf16(g, s);
+}
+
 __global__ void zero_diag_kernel(float* sim, int n, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) sim[(i / n) * (int64_t)n * n + (i % n) * (int64_t)(n + 1)] = 0.f;
@@ -243,6 +256,7 @@ struct Plan {
   float *lse, *lse1, *attn_cls, *attn_diag, *out_last, *y; int32_t *idx_out, *idx_sa; void* refine_scratch;
   float *scores, *probs;
   float *omega, *qnorm, *knorm;
+  uint8_t *x8, *h8; float *sx8, *sh8;                     // SG_PREC_FP8: quantised LN output / GELU output + per-row scales
   float *attn_avg, *sa_tmp, *sa_qk32, *sa_scores, *sa_probs;   // self-attention enhancement, mode='attention'
   // GEM
   float* x_gem; void* gnorm[3]; void* gatt[3]; float* inv_temp; float* gem_out; void* ctx2;
@@ -262,6 +276,11 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.qkv = b.take(R * 3 * d.width * e);
   p.ctx = b.take(R * d.width * e);
   p.hbuf = b.take(R * d.mlp_width * e);
+  p.x8 = p.h8 = nullptr; p.sx8 = p.sh8 = nullptr;
+  if (c->fp8) {
+    p.x8 = (uint8_t*)b.take(R * d.width); p.sx8 = b.get<float>(R);
+    p.h8 = (uint8_t*)b.take(R * d.mlp_width); p.sh8 = b.get<float>(R);
+  }
   p.xhat = nullptr; p.sim = nullptr;
   if (o->similarity_enabled) { p.xhat = b.take((size_t)B * n * d.width * e); p.sim = b.get<float>((size_t)B * n * n); }
   p.lse = b.get<float>((size_t)B * d.heads * N);
@@ -333,13 +352,24 @@ extern "C" int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias,
   SG_REQUIRE(A && W && C, "sg_gemm_bf16_raw: null pointer");
   return linear(true, A, K, W, bias, residual, C, N, !c_is_bf16, M, N, K, act, as_stream(st));
 }
+// fp8 (OCP e4m3) GEMM on caller-quantised operands: A8 [M,K] with per-row scales sa [M], W8 [N,K] with per-row scales sw [N], K % 128 == 0.
+extern "C" int sg_gemm_fp8_raw(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, const float* residual,
+                               void* C, int M, int N, int K, int act, int c_is_bf16, sg_stream st) {
+  SG_REQUIRE(A8 && W8 && sa && sw && C, "sg_gemm_fp8_raw: null pointer");
+  return linear_fp8((const uint8_t*)A8, sa, K, (const uint8_t*)W8, sw, bias, residual, C, N, !c_is_bf16, M, N, K, act, as_stream(st));
+}
+// rows of f32 -> e4m3 + per-row absmax scale (scale[r] = max|x[r,:]| / 448), the quantiser both fp8 operands go through
+extern "C" int sg_quantize_rows_fp8(const float* x, int64_t rows, int D, void* y, float* scale, sg_stream st) {
+  SG_REQUIRE(x && y && scale && rows > 0 && D > 0, "sg_quantize_rows_fp8: bad arguments");
+  return quantize_rows_fp8(x, 0, D, (uint8_t*)y, D, scale, rows, D, as_stream(st));
+}
 // Tuning hook for the bf16 GEMM tile configuration (-1 = automatic).
 extern "C" int sg_set_gemm_config(int cfg) {
   set_gemm_config(cfg);
   return SG_OK;
 }
 extern "C" int sg_profile_disable(void) { g_prof.on = false; return SG_OK; }
-// category: 0 bf16 GEMM (non-persistent tile variants), 1 fused attention, 2 f32 GEMM, 3 the persistent bf16 GEMM.  Call after the stream
+// category: 0 bf16 GEMM (non-persistent tile variants), 1 fused attention, 2 f32 GEMM, 3 the persistent bf16 GEMM, 4 fp8 GEMM.  Call after the stream
 // has been synchronised.
 extern "C" int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped) {
   SG_REQUIRE(category >= 0 && category < PROF_NCAT && total_ms && total_flops && launches, "sg_profile_read: bad argument");
@@ -359,16 +389,19 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
   const sg_vit_desc& d = *desc;
   SG_REQUIRE(d.width > 0 && d.layers >= 2 && d.heads > 0 && d.width % d.heads == 0 && d.patch > 0 && d.embed_dim > 0 && d.grid0 > 0 &&
              d.mlp_width > 0, "sg_create: bad descriptor");
-  SG_REQUIRE(d.precision == SG_PREC_F32 || d.precision == SG_PREC_BF16, "sg_create: bad precision %d", d.precision);
+  SG_REQUIRE(d.precision == SG_PREC_F32 || d.precision == SG_PREC_BF16 || d.precision == SG_PREC_FP8, "sg_create: bad precision %d", d.precision);
   SG_REQUIRE(d.width % 4 == 0 && d.embed_dim % 4 == 0, "sg_create: width / embed_dim must be multiples of 4");
-  if (d.precision == SG_PREC_BF16) {
+  if (d.precision == SG_PREC_FP8)
+    SG_REQUIRE(d.width % 128 == 0 && d.mlp_width % 128 == 0, "sg_create: fp8 mode needs width and mlp_width to be multiples of 128");
+  if (d.precision != SG_PREC_F32) {
     SG_REQUIRE(d.width % 64 == 0 && d.mlp_width % 64 == 0, "sg_create: bf16 mode needs width and mlp_width to be multiples of 64");
     const int dh = d.width / d.heads;
     SG_REQUIRE(dh == 32 || dh == 64 || dh == 80 || dh == 128, "sg_create: bf16 mode supports head_dim 32/64/80/128, got %d", dh);
   }
   SG_HIP(hipSetDevice(device));
   sg_context* c = new sg_context();
-  c->d = d; c->device = device; c->bf16 = d.precision == SG_PREC_BF16; c->esz = c->bf16 ? 2 : 4;
+  c->d = d; c->device = device; c->bf16 = d.precision != SG_PREC_F32; c->fp8 = d.precision == SG_PREC_FP8;
+  c->esz = c->bf16 ? 2 : 4;
   c->Kpatch = 3 * d.patch * d.patch;
   c->Kpad = (int)align_up(c->Kpatch, 64);
   c->finalized = false;
@@ -389,6 +422,11 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
       L.w_fc = bb.take((size_t)M * D * e); L.w_proj = bb.take((size_t)D * M * e);
       L.b_qkv = bb.get<float>(3 * D); L.b_out = bb.get<float>(D); L.b_fc = bb.get<float>(M); L.b_proj = bb.get<float>(D);
       L.ln1_g = bb.get<float>(D); L.ln1_b = bb.get<float>(D); L.ln2_g = bb.get<float>(D); L.ln2_b = bb.get<float>(D);
+      L.w_qkv8 = L.w_fc8 = L.w_proj8 = nullptr; L.s_qkv = L.s_fc = L.s_proj = nullptr;
+      if (c->fp8) {
+        L.w_qkv8 = (uint8_t*)bb.take((size_t)3 * D * D); L.w_fc8 = (uint8_t*)bb.take((size_t)M * D); L.w_proj8 = (uint8_t*)bb.take((size_t)D * M);
+        L.s_qkv = bb.get<float>(3 * D); L.s_fc = bb.get<float>(M); L.s_proj = bb.get<float>(D);
+      }
     }
   };
   lay(b);
@@ -444,15 +482,21 @@ extern "C" int sg_vit_set_tensor(sg_context* c, const char* name, const float* s
         switch (t) {
           case 0: rc = copyf(L.ln1_g, D); break;
           case 1: rc = copyf(L.ln1_b, D); break;
-          case 2: rc = packw(L.w_qkv, 3 * D, D, D); break;
+          case 2: rc = packw(L.w_qkv, 3 * D, D, D);
+                  if (rc == SG_OK && c->fp8) rc = quantize_rows_fp8(src, 0, D, L.w_qkv8, D, L.s_qkv, 3 * D, D, s);
+                  break;
           case 3: rc = copyf(L.b_qkv, 3 * D); break;
           case 4: rc = packw(L.w_out, D, D, D); break;
           case 5: rc = copyf(L.b_out, D); break;
           case 6: rc = copyf(L.ln2_g, D); break;
           case 7: rc = copyf(L.ln2_b, D); break;
-          case 8: rc = packw(L.w_fc, M, D, D); break;
+          case 8: rc = packw(L.w_fc, M, D, D);
+                  if (rc == SG_OK && c->fp8) rc = quantize_rows_fp8(src, 0, D, L.w_fc8, D, L.s_fc, M, D, s);
+                  break;
           case 9: rc = copyf(L.b_fc, M); break;
-          case 10: rc = packw(L.w_proj, D, M, M); break;
+          case 10: rc = packw(L.w_proj, D, M, M);
+                   if (rc == SG_OK && c->fp8) rc = quantize_rows_fp8(src, 0, M, L.w_proj8, M, L.s_proj, D, M, s);
+                   break;
           case 11: rc = copyf(L.b_proj, D); break;
         }
       }
@@ -484,6 +528,12 @@ static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
   const sg_vit_desc& d = c->d;
   const int D = d.width, M = d.mlp_width;
   const int act = d.quick_gelu ? ACT_QUICK_GELU : ACT_GELU;
+  if (c->fp8 && p.x8 && L.w_fc8) {                          // fp8 linears: LN -> e4m3 + row scale; GELU output re-quantised per row
+    SG_TRY(layernorm_fp8(x, D, L.ln2_g, L.ln2_b, p.x8, D, p.sx8, R, D, 1e-5f, s));
+    SG_TRY(linear_fp8(p.x8, p.sx8, D, L.w_fc8, L.s_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
+    SG_TRY(quantize_rows_fp8(p.hbuf, 1, M, p.h8, M, p.sh8, R, M, s));
+    return linear_fp8(p.h8, p.sh8, M, L.w_proj8, L.s_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s);
+  }
   SG_TRY(layernorm(x, D, L.ln2_g, L.ln2_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
   SG_TRY(linear(c->bf16, p.xn, D, L.w_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
   SG_TRY(linear(c->bf16, p.hbuf, M, L.w_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s));
@@ -498,8 +548,13 @@ static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
   const int D = d.width, H = d.heads;
   const int64_t R = (int64_t)B * N;
   AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1, p.omega, p.qnorm, p.knorm};
-  SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
-  SG_TRY(linear(c->bf16, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+  if (c->fp8 && p.x8 && L.w_qkv8) {
+    SG_TRY(layernorm_fp8(x, D, L.ln1_g, L.ln1_b, p.x8, D, p.sx8, R, D, 1e-5f, s));
+    SG_TRY(linear_fp8(p.x8, p.sx8, D, L.w_qkv8, L.s_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+  } else {
+    SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+    SG_TRY(linear(c->bf16, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+  }
   SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s, causal));
   if (stats)
     SG_TRY(attention_stats(p.qkv, c->bf16, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), p.attn_cls,

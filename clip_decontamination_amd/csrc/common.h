@@ -87,7 +87,7 @@ __device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + e
 enum Act { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
 
 // ---- optional live kernel timing (bench.py roofline): HIP events around the launches of one kernel family ----
-enum ProfCat { PROF_GEMM_BF16 = 0, PROF_ATTENTION = 1, PROF_GEMM_F32 = 2, PROF_GEMM_PERSIST = 3, PROF_NCAT = 4 };   // 3: the persistent bf16 kernel alone (the dominant kernel bench.py prices)
+enum ProfCat { PROF_GEMM_BF16 = 0, PROF_ATTENTION = 1, PROF_GEMM_F32 = 2, PROF_GEMM_PERSIST = 3, PROF_GEMM_FP8 = 4, PROF_NCAT = 5 };   // 3: the persistent bf16 kernel alone (the dominant kernel bench.py prices)
 bool prof_on();
 void prof_begin(int cat, double work, hipStream_t s);   // work = algorithmic FLOPs of the launch
 void prof_end(int cat, hipStream_t s);
@@ -102,6 +102,9 @@ struct GemmBf16Args {
   void* C; int64_t ldc; int64_t strideC; int c_is_bf16;
   int M, N, K, batch, act;
   float alpha;                                        // applied to the accumulator before bias
+  // fp8 mode (fp8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K % 128 == 0); lda / ldw / K stay in ELEMENTS (= bytes);
+  // the accumulator is de-quantised with row_scale[m] * col_scale[n] (per-token / per-output-channel absmax scales).
+  int fp8; const float* row_scale; const float* col_scale;
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
 void set_gemm_config(int c);   // tuning hook: -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants

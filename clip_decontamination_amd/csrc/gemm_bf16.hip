@@ -154,19 +154,23 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
                                                int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
-  float4 bias4[NI];
+  float4 bias4[NI], cs4[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int n = col0 + j * 16 + (lane >> 4) * 4;
     bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cs4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
     if (a.bias && n + 3 < a.N) bias4[j] = *reinterpret_cast<const float4*>(a.bias + n);
+    if (a.col_scale && n + 3 < a.N) cs4[j] = *reinterpret_cast<const float4*>(a.col_scale + n);
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    float al = a.alpha;
+    if (a.row_scale) { int m = row0 + i * 16 + (lane & 15); m = m < a.M ? m : a.M - 1; al *= a.row_scale[m]; }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      float v[4] = {acc[i][j][0] * a.alpha + bias4[j].x, acc[i][j][1] * a.alpha + bias4[j].y, acc[i][j][2] * a.alpha + bias4[j].z,
-                    acc[i][j][3] * a.alpha + bias4[j].w};
+      float v[4] = {acc[i][j][0] * (al * cs4[j].x) + bias4[j].x, acc[i][j][1] * (al * cs4[j].y) + bias4[j].y,
+                    acc[i][j][2] * (al * cs4[j].z) + bias4[j].z, acc[i][j][3] * (al * cs4[j].w) + bias4[j].w};
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -225,7 +229,11 @@ __device__ __forceinline__ bf16x8 read_frag32(const char* tile, int row, int chu
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
+// FP8: the operands are OCP e4m3 bytes.  The kernel is handed the SAME byte image as a bf16 matrix of half the width (K tile of
+// 64 'bf16' = 128 fp8 per row), so staging, swizzle and fragment reads are unchanged; the two 16-byte fragment reads of a K tile
+// are concatenated into the 32-byte operand of ONE v_mfma_f32_16x16x128_f8f6f4 (both operands use the same K permutation).
+// The legacy v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate on gfx950 (tools/mfma_rate.hip: 2.1 vs 4.8 PFLOP/s), so it is not used.
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MI = TM / 16, NI = TN / 16;
   constexpr int RPS = BKT == 64 ? 8 : 16;                // rows per 1 KiB slab (row = BKT * 2 bytes)
@@ -286,6 +294,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
     if (ABLATE != 1 && t + STAGES - 1 < nt) stage(t + STAGES - 1, (t + STAGES - 1) % STAGES);
     const char* bufA = lds + (t % STAGES) * STAGE_BYTES;
     const char* bufW = bufA + BM_ * BKT * 2;
+    if constexpr (FP8) {
+      static_assert(!FP8 || BKT == 64, "fp8 uses the 128-byte K tile");
+      typedef __attribute__((ext_vector_type(8))) int i32x8;
+      union Op { bf16x8 h[2]; i32x8 v; };
+      Op fa8[MI], fw8[NI];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa8[i].h[kk] = read_frag(bufA, wave_m * TM + i * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fw8[j].h[kk] = read_frag(bufW, wave_n * TN + j * 16 + (lane & 15), chunk);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)   // cbsz = blgp = 0: both operands e4m3; scales 0x7f = 2^0 (E8M0), i.e. plain fp8 x fp8
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw8[j].v, fa8[i].v, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < BKT / 32; ++kk) {
       const int chunk = kk * 4 + (lane >> 4);
@@ -329,6 +357,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
       const int n = n0 + wave_n * TN + j * 16 + (lane >> 4) * 4;
       if (n >= a.N) continue;
       float v[4] = {acc[i][j][0] * a.alpha, acc[i][j][1] * a.alpha, acc[i][j][2] * a.alpha, acc[i][j][3] * a.alpha};
+      if (a.row_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a.row_scale[m];
+      }
+      if (a.col_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a.col_scale[n + e < a.N ? n + e : a.N - 1];
+      }
       if (vec) {
         if (a.bias) {
           const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
@@ -974,9 +1010,9 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s, int place = 0) {
 static int g_gemm_config = -1;                             // -1 = pick per shape
 void set_gemm_config(int c) { g_gemm_config = c; }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false>
 static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
-  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT>;
+  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8>;
   const size_t lds = (size_t)STAGES * (BM_ + BN_) * BKT * 2;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
@@ -995,8 +1031,29 @@ static void launch(const GemmBf16Args& a, bool vec, dim3 grid, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_bf16_kernel<ACT, C_BF16, false>), grid, dim3(256), 0, s, a);
 }
 
+static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
+  SG_REQUIRE(a.K % 128 == 0, "gemm_fp8: K=%d must be a multiple of 128", a.K);
+  SG_REQUIRE(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.strideA % 16 == 0 && a.strideW % 16 == 0, "gemm_fp8: operand strides must be multiples of 16 bytes");
+  SG_REQUIRE((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0, "gemm_fp8: operands must be 16-byte aligned");
+  SG_REQUIRE(a.row_scale && a.col_scale, "gemm_fp8: row_scale / col_scale are required");
+  SG_REQUIRE(a.act >= 0 && a.act <= 2, "gemm_fp8: bad act %d", a.act);
+  bool vec = (a.N % 8 == 0) && (a.ldc % 8 == 0) && (a.strideC % 8 == 0) && ((((uintptr_t)a.C) & 15) == 0) && ((((uintptr_t)a.col_scale) & 15) == 0);
+  if (a.bias) vec = vec && ((((uintptr_t)a.bias) & 15) == 0);
+  if (a.residual) vec = vec && (a.ldr % 4 == 0) && ((((uintptr_t)a.residual) & 15) == 0);
+  GemmBf16Args h = a;                                       // the same bytes seen as a bf16 matrix of half the width
+  h.K = a.K / 2; h.lda = a.lda / 2; h.ldw = a.ldw / 2; h.strideA = a.strideA / 2; h.strideW = a.strideW / 2;
+  prof_begin(PROF_GEMM_FP8, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
+  const int rc = (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 128, 4, 2, 3, 0, 64, true>(h, vec, s)
+                                             : launch_ring<128, 128, 2, 2, 3, 0, 64, true>(h, vec, s);
+  prof_end(PROF_GEMM_FP8, s);
+  if (rc != SG_OK) return rc;
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   SG_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.fp8) return gemm_fp8(a, s);
   SG_REQUIRE(a.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d (pad the operands)", a.K, BK);
   SG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.strideA % 8 == 0 && a.strideW % 8 == 0,
              "gemm_bf16: operand strides must be multiples of 8 elements (16-byte chunks)");

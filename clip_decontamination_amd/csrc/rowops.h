@@ -7,6 +7,10 @@ namespace sg {
 
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int y_is_bf16,
               int64_t rows, int D, float eps, hipStream_t s);
+// fp8 (OCP e4m3) operands of the fp8 GEMMs: per-row absmax scale (scale[r] = max|row| / 448)
+int layernorm_fp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* y, int64_t ldy, float* scale, int64_t rows,
+                  int D, float eps, hipStream_t s);
+int quantize_rows_fp8(const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, float* scale, int64_t rows, int D, hipStream_t s);
 int embed_assemble(const float* patches, int64_t ldp, const float* cls_emb, const float* pos, const float* gamma,
                    const float* beta, float* x, int B, int N, int D, float eps, hipStream_t s);
 int posembed_resize(const float* pos, int g0, int D, int gh, int gw, int antialias, float* out, hipStream_t s);

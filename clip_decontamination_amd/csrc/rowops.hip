@@ -77,6 +77,107 @@ int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta
   return SG_OK;
 }
 
+// ---- fp8 (OCP e4m3) row quantisation ------------------------------------------------------------------------------------------
+// q[r,:] = e4m3(v[r,:] / scale[r]),  scale[r] = max|v[r,:]| / 448  (per-token dynamic scale; per-output-channel for weights).
+// v_cvt_pk_fp8_f32 rounds to nearest even; |v| / scale <= 448 by construction, so nothing saturates.
+constexpr float FP8_MAX = 448.0f;
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+
+// LayerNorm whose output goes straight to fp8 + a per-row scale (the A operand of the fp8 QKV / fc GEMMs): one wave per row
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, uint8_t* __restrict__ y, int64_t ldy,
+                                                            float* __restrict__ scale, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float4 v[LN_MAX_VEC];
+  const int nv = D >> 2;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+    if (lane + 64 * i < nv) v[i] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * i));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+    if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+    if (lane + 64 * i < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * idx);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * idx);
+      v[i] = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y, (v[i].z - mean) * rstd * g.z + b.z,
+                         (v[i].w - mean) * rstd * g.w + b.w);
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    }
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
+  const float inv = 1.0f / sc;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) *reinterpret_cast<uint32_t*>(y + row * ldy + 4 * idx) = pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+  }
+  if (lane == 0) scale[row] = sc;
+}
+
+int layernorm_fp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* y, int64_t ldy, float* scale, int64_t rows,
+                  int D, float eps, hipStream_t s) {
+  SG_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAX_VEC, "layernorm_fp8: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * LN_MAX_VEC);
+  SG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm_fp8: row strides must be multiples of 4");
+  if (rows == 0) return SG_OK;
+  hipLaunchKernelGGL(layernorm_fp8_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, scale, rows, D, eps);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// rows of f32 or bf16 -> fp8 + per-row scale (weights at load time; the GELU output in front of the fp8 proj GEMM): one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restrict__ x, int64_t ldx, uint8_t* __restrict__ y, int64_t ldy,
+                                                                float* __restrict__ scale, int64_t rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float amax = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(to_f32<T>(xr[c + e])));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
+  const float inv = 1.0f / sc;
+  for (int c = lane * 4; c < D; c += 256)
+    *reinterpret_cast<uint32_t*>(y + row * ldy + c) =
+        pack_fp8x4(to_f32<T>(xr[c]) * inv, to_f32<T>(xr[c + 1]) * inv, to_f32<T>(xr[c + 2]) * inv, to_f32<T>(xr[c + 3]) * inv);
+  if (lane == 0) scale[row] = sc;
+}
+
+int quantize_rows_fp8(const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, float* scale, int64_t rows, int D, hipStream_t s) {
+  SG_REQUIRE(D % 4 == 0 && ldy % 4 == 0, "quantize_rows_fp8: D=%d and the output stride must be multiples of 4", D);
+  if (rows == 0) return SG_OK;
+  dim3 grid((unsigned)cdiv(rows, 4));
+  if (x_is_bf16) hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, y, ldy, scale, rows, D);
+  else hipLaunchKernelGGL(quantize_rows_fp8_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, y, ldy, scale, rows, D);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
 // x[b,t,:] = ln_pre( (t == 0 ? class_embedding : patch_embed[b, t-1, :]) + pos[t, :] )
 // reference open_clip/transformer.py:565-574
 __global__ __launch_bounds__(256) void embed_assemble_kernel(const float* __restrict__ patches, int64_t ldp,

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F32, MODEL_TYPES, check
+from ._lib import PREC_BF16, PREC_F32, PREC_FP8, MODEL_TYPES, check
 
 
 def _require_gpu(*tensors):
@@ -33,6 +33,8 @@ def precision_id(precision) -> int:
         return PREC_F32
     if precision in (PREC_BF16, "bf16", torch.bfloat16):
         return PREC_BF16
+    if precision in (PREC_FP8, "fp8"):
+        return PREC_FP8
     raise ValueError(f"unknown precision {precision!r}")
 
 
@@ -66,6 +68,33 @@ def linear(A, W, bias=None, residual=None, act: int = 0, precision="bf16"):
     check(lib.sg_op_linear(ptr(A), ptr(W), ptr(bias), ptr(residual), ptr(out), M, N, K, act, precision_id(precision), sp, sn,
                            stream_ptr()), "sg_op_linear")
     return out
+
+
+def quantize_rows_fp8(x):
+    """f32 [rows, D] -> (uint8 e4m3 [rows, D], f32 scales [rows]); scale = max|row| / 448."""
+    lib = _lib.load()
+    x = _f32(x)
+    _require_gpu(x)
+    rows, D = x.shape
+    q = torch.empty(rows, D, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.sg_quantize_rows_fp8(ptr(x), rows, D, ptr(q), ptr(sc), stream_ptr()), "sg_quantize_rows_fp8")
+    return q, sc
+
+
+def linear_fp8(A, W, bias=None, residual=None, act: int = 0, out_bf16: bool = False):
+    """act(dequant(fp8(A) @ fp8(W)^T) + bias) (+ residual) on the fp8 MFMA path; A [M,K], W [N,K] f32, K % 128 == 0."""
+    lib = _lib.load()
+    a8, sa = quantize_rows_fp8(A)
+    w8, sw = quantize_rows_fp8(W)
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=A.device)
+    bias = None if bias is None else _f32(bias)
+    residual = None if residual is None else _f32(residual)
+    check(lib.sg_gemm_fp8_raw(ptr(a8), ptr(sa), ptr(w8), ptr(sw), ptr(bias), ptr(residual), ptr(out), M, N, K, act, int(out_bf16),
+                              stream_ptr()), "sg_gemm_fp8_raw")
+    return out, (a8, sa, w8, sw)
 
 
 def layernorm(x, gamma, beta, eps: float = 1e-5):

@@ -38,6 +38,8 @@ enum sg_status {
 enum sg_precision {       /* arithmetic the ViT GEMMs / attention run in */
   SG_PREC_F32 = 0,        /* parity mode: f32 MFMA (exact fmaf chains), materialised attention */
   SG_PREC_BF16 = 1,       /* throughput mode: bf16 MFMA, f32 accumulate, f32 residual stream + LN */
+  SG_PREC_FP8 = 2,        /* bf16 mode whose QKV / fc / proj linears of the ordinary blocks run on fp8 (OCP e4m3) MFMA with per-token and
+                             per-output-channel absmax scales; attention, out-proj, the last block and everything else stay bf16 / f32 */
 };
 
 /* last-block attention variants: reference open_clip/transformer.py:858-932 (custom_attn),
@@ -108,7 +110,8 @@ int sg_version(void);
 /* ---- live kernel timing (measurement only; used by bench.py's roofline) -------------------------
  * HIP events bracket every launch of a kernel family on the stream it is launched on.
  * category: 0 = bf16 MFMA GEMM (small-shape tile variants), 1 = fused attention, 2 = f32 MFMA GEMM,
- *           3 = the persistent bf16 GEMM (every large ViT linear; the kernel bench.py's roofline prices).  Read after synchronising. */
+ *           3 = the persistent bf16 GEMM (every large ViT linear; the kernel bench.py's roofline prices), 4 = fp8 GEMM.
+ *           Read after synchronising. */
 int sg_profile_enable(int capacity);
 int sg_profile_disable(void);
 int sg_set_gemm_config(int cfg);   /* tuning hook: bf16 GEMM tile variant, -1 = automatic */
@@ -196,6 +199,11 @@ int sg_op_linear(const float* A, const float* W, const float* bias, const float*
 /* bf16 GEMM on caller-packed operands: A [M,K], W [N,K] bf16 (K % 64 == 0), C bf16 or f32 */
 int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                      int act, int c_is_bf16, sg_stream s);
+/* fp8 (OCP e4m3, v_mfma_f32_16x16x128_f8f6f4) GEMM on quantised operands: C = act((A8 . W8^T) * sa[m] * sw[n] + bias) (+ residual);
+ * A8 [M,K], W8 [N,K] bytes, K % 128 == 0; sg_quantize_rows_fp8 produces an operand and its per-row scales (absmax / 448). */
+int sg_gemm_fp8_raw(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, const float* residual, void* C,
+                    int M, int N, int K, int act, int c_is_bf16, sg_stream s);
+int sg_quantize_rows_fp8(const float* x, int64_t rows, int D, void* y, float* scale, sg_stream s);
 int sg_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, sg_stream s);
 /* multi-term attention over packed qkv [B,N,3D] (rows q|k|v, nn.MultiheadAttention order);
  * variant = enum sg_model_type (SG_VANILLA = ordinary softmax(q k^T) v). bias: [B,n,n] or NULL.

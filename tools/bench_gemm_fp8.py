@@ -1,0 +1,36 @@
+"""fp8 GEMM (v_mfma_f32_16x16x128_f8f6f4 ring kernel) on the ViT-L/14 linear shapes, random operands; bf16 persistent kernel beside it."""
+import ctypes as C
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from clip_decontamination_amd import _lib, ops
+
+lib = _lib.load()
+dev = "cuda:0"
+M = int(os.environ.get("GEMM_TILES", "128")) * 1370
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+for name, m, n, k, act, cbf in [("qkv", M, 3072, 1024, 0, 1), ("fc", M, 4096, 1024, 1, 1), ("proj", M, 1024, 4096, 0, 0)]:
+    A = torch.randn(m, k, device=dev)
+    W = torch.randn(n, k, device=dev) * k ** -0.5
+    a8, sa = ops.quantize_rows_fp8(A)
+    w8, sw = ops.quantize_rows_fp8(W)
+    A16, W16 = A.bfloat16(), W.bfloat16()
+    del A, W
+    bias = torch.randn(n, device=dev)
+    Cc = torch.empty(m, n, device=dev, dtype=torch.bfloat16 if cbf else torch.float32)
+    R = None if cbf else torch.randn(m, n, device=dev)
+    for label, fn in (("fp8", lambda: lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)),
+                      ("bf16", lambda: lib.sg_gemm_bf16_raw(P(A16), P(W16), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream))):
+        assert fn() == 0, lib.sg_last_error()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 10)
+        med = sorted(ts)[2]
+        print(f"{name:5s} {label:5s}: {med * 1e3:8.1f} us -> {2.0 * m * n * k / med / 1e9:7.1f} TFLOP/s", flush=True)
