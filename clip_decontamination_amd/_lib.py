@@ -74,6 +74,7 @@ SIGNATURES = {
     "sg_op_attention_scratch_bytes": (Z, [I, I, I, I, I]),
     "sg_op_attention": (I, [P, I, I, I, I, I, P, F, P, P, P, I, P, Z, P]),
     "sg_adaptive_conv": (I, [P, P, I, I, I, I, I, P, P]),
+    "sg_render_maps": (I, [P, P, P, I, I, I, P, P, P]),
     "sg_ctd_scratch_bytes": (Z, [I, I, I]),
     "sg_ctd_debias": (I, [P, P, I, I, I, C.c_double, I, F, I, P, P, Z, P]),
     "sg_text_create": (I, [C.POINTER(P), I, I, I, I, I, I, I, I, I]),

@@ -164,9 +164,43 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
   labels[i] = arg;
 }
 
+// ---- label / confidence images (segmentor.py:501-531, 580-608) ---------------------------------------------------------
+// mask  = palette[clip(label, 0, K-1)]                                (_colorize_mask)
+// heat  = (g, 0, 255 - g), g = uint8(clip(nan_to_num(max_k probs), 0, 1) * 255)   (_to_colormap, the branch without OpenCV)
+__global__ __launch_bounds__(256) void render_maps_kernel(const int64_t* __restrict__ labels, const float* __restrict__ probs,
+                                                          const uint8_t* __restrict__ palette, int K, int64_t HW,
+                                                          uint8_t* __restrict__ mask_rgb, uint8_t* __restrict__ heat_rgb) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  if (mask_rgb) {
+    int64_t l = labels[i];
+    l = l < 0 ? 0 : (l > K - 1 ? K - 1 : l);
+    mask_rgb[3 * i + 0] = palette[3 * l + 0]; mask_rgb[3 * i + 1] = palette[3 * l + 1]; mask_rgb[3 * i + 2] = palette[3 * l + 2];
+  }
+  if (heat_rgb) {
+    float c = -INFINITY;
+    for (int k = 0; k < K; ++k) { const float v = probs[(int64_t)k * HW + i]; c = (v > c || v != v) ? v : c; }   // torch.max propagates NaN
+    if (c != c) c = 0.f;
+    c = fminf(fmaxf(c, 0.f), 1.f);
+    const uint8_t g = (uint8_t)(c * 255.0f);
+    heat_rgb[3 * i + 0] = g; heat_rgb[3 * i + 1] = 0; heat_rgb[3 * i + 2] = (uint8_t)(255 - g);
+  }
+}
+
 }  // namespace sg
 
 using namespace sg;
+
+extern "C" int sg_render_maps(const int64_t* labels, const float* probs, const uint8_t* palette, int K, int H, int W, uint8_t* mask_rgb,
+                              uint8_t* heat_rgb, sg_stream s) {
+  SG_REQUIRE(K > 0 && H > 0 && W > 0, "sg_render_maps: bad shape");
+  SG_REQUIRE(!mask_rgb || (labels && palette), "sg_render_maps: the mask needs labels and a palette");
+  SG_REQUIRE(!heat_rgb || probs, "sg_render_maps: the heat map needs the class probabilities");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(render_maps_kernel, dim3((unsigned)cdiv(HW, 256)), dim3(256), 0, as_stream(s), labels, probs, palette, K, HW, mask_rgb, heat_rgb);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
 
 extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const float* text, int B, int n, int E, int Q,
                                 float global_debias_factor, float cls_token_lambda, float* logits, sg_stream s) {

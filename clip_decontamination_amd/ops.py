@@ -226,6 +226,21 @@ def postprocess(logits, query_idx, num_classes: int, logit_scale: float, prob_th
     return probs, labels
 
 
+def render_maps(labels, probs, palette, want_mask: bool = True, want_heat: bool = True):
+    """labels int64 [1,H,W] or [H,W], probs [K,H,W], palette uint8 [K,3] -> (mask uint8 [H,W,3] | None, heat uint8 [H,W,3] | None)."""
+    lib = _lib.load()
+    labels = labels.reshape(labels.shape[-2], labels.shape[-1]).contiguous()
+    _require_gpu(labels, probs)
+    H, W = labels.shape
+    K = int(palette.shape[0])
+    pal = palette.to(device=labels.device, dtype=torch.uint8).contiguous()
+    probs = None if probs is None else _f32(probs)
+    mask = torch.empty(H, W, 3, dtype=torch.uint8, device=labels.device) if want_mask else None
+    heat = torch.empty(H, W, 3, dtype=torch.uint8, device=labels.device) if want_heat else None
+    check(lib.sg_render_maps(ptr(labels), ptr(probs), ptr(pal), K, H, W, ptr(mask), ptr(heat), stream_ptr()), "sg_render_maps")
+    return mask, heat
+
+
 def adaptive_conv(inp, filters):
     """FeatUp AdaptiveConv.apply: inp [B,C,h+d-1,w+d-1], filters [B,h,w,d,d] -> [B,C,h,w]."""
     lib = _lib.load()

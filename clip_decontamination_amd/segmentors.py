@@ -261,7 +261,42 @@ class _HipSegmentorBase(_Base):
             if data_samples is None:
                 return seg_pred
             data_samples[i].set_data({"seg_logits": PixelData(**{"data": probs}), "pred_sem_seg": PixelData(**{"data": seg_pred})})
+            if getattr(self, "result_dir", None) or getattr(self, "heatmap_dir", None):        # segmentor.py:501-531
+                self._write_maps(probs, seg_pred, data_samples[i], i)
         return data_samples
+
+    def _generate_palette(self, n):
+        """Reference segmentor.py:568-578: deterministic HSV palette, the background class dimmed."""
+        import colorsys
+        palette = []
+        for idx in range(n):
+            r, g, b = colorsys.hsv_to_rgb((idx / max(1, n)) % 1.0, 0.75, 1.0 if idx != self.bg_idx else 0.2)
+            palette.append([int(r * 255), int(g * 255), int(b * 255)])
+        return np.array(palette, dtype=np.uint8)
+
+    def _write_maps(self, probs, seg_pred, sample, i):
+        """Colour mask -> result_dir/<stem>.png, confidence map -> heatmap_dir/<stem>.png.  The images are rendered on the device
+        (sg_render_maps); only the PNG encoding is host work.  Without OpenCV the reference's own fall-back colour ramp is used."""
+        from . import ops
+        from PIL import Image
+        meta = sample.metainfo if hasattr(sample, "metainfo") else {}
+        stem = None
+        for key in ("img_path", "ori_path", "filename", "ori_filename"):
+            if key in meta and meta[key]:
+                stem = os.path.splitext(os.path.basename(meta[key]))[0]
+                break
+        if stem is None:
+            stem = f"sample_{i}"
+        palette = getattr(self, "_palette_cache", None)
+        if palette is None or len(palette) < self.num_classes:
+            palette = self._palette_cache = self._generate_palette(self.num_classes)
+        mask, heat = ops.render_maps(seg_pred, probs, torch.from_numpy(palette), want_mask=bool(self.result_dir), want_heat=bool(self.heatmap_dir))
+        if self.result_dir:
+            os.makedirs(self.result_dir, exist_ok=True)
+            Image.fromarray(mask.cpu().numpy()).save(os.path.join(self.result_dir, f"{stem}.png"))
+        if self.heatmap_dir:
+            os.makedirs(self.heatmap_dir, exist_ok=True)
+            Image.fromarray(heat.cpu().numpy()).save(os.path.join(self.heatmap_dir, f"{stem}.png"))
 
     def compute_padsize(self, H: int, W: int, patch_size: int):
         return compute_padsize(H, W, patch_size)

@@ -158,6 +158,11 @@ int sg_resize_bilinear(const float* src, int C, int h, int w, float* dst, int H,
  *   logits [Q,H,W]; query_idx int32 [Q]; probs [K,H,W] f32 (may be NULL); labels int64 [H,W]. */
 int sg_postprocess(const float* logits, const int32_t* query_idx, int Q, int K, int H, int W, float logit_scale,
                    float prob_thd, int bg_idx, float* probs, int64_t* labels, sg_stream s);
+/* Label / confidence images of postprocess_result (segmentor.py:501-531): mask_rgb [H,W,3] = palette[clip(label)] (_colorize_mask,
+ * :580-590); heat_rgb [H,W,3] = (g, 0, 255-g) with g = uint8(clip(max_k probs, 0, 1) * 255) (_to_colormap without OpenCV, :604-608;
+ * OpenCV's JET table is not reproduced).  Either output may be NULL. */
+int sg_render_maps(const int64_t* labels, const float* probs, const uint8_t* palette, int K, int H, int W, uint8_t* mask_rgb,
+                   uint8_t* heat_rgb, sg_stream s);
 
 /* ---- token refinements as stand-alone ops (same arithmetic as inside sg_vit_forward) ----------
  * sg_outlier_suppress replaces OutlierSuppressionModule.forward (outlier_suppression.py:83-214):

@@ -353,6 +353,18 @@ def gen_segment():
             ff = s.forward_feature(img[:, :, :fc, :fc], (40, 44))
             close(o.forward_feature(img[:, :, :fc, :fc], (40, 44)), ff, 3e-5, f"{name} forward_feature")
             out.update({f"{name}.img": img, f"{name}.logits": logits, f"{name}.pred": pred, f"{name}.ff": ff})
+            if name == "ex_base":
+                # label / confidence images by the reference's own helpers (segmentor.py:568-608); its OpenCV-less branch of
+                # _to_colormap is the one exercised (cv2 is a stub here; the JET table lives inside OpenCV)
+                mod = R.ref("segmentor")
+                saved, mod.cv2 = mod.cv2, None
+                try:
+                    probs_ref = o.postprocess(ol[0])[0]
+                    out["viz.mask"] = s._colorize_mask(pred.squeeze(0).numpy())
+                    out["viz.heat"] = s._to_colormap(probs_ref.max(dim=0)[0].numpy())
+                    out["viz.palette"] = s._generate_palette(s.num_classes)
+                finally:
+                    mod.cv2 = saved
         # GEM through segearth_segmentor.Segmentor (the only class where GEM runs, R5)
         gcfg = Wt.vit_config("tiny-gem")
         gnp = Wt.make_vit_weights(gcfg, seed=0)

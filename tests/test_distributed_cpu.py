@@ -36,6 +36,29 @@ def _worker(rank, world, port, n_tiles_expected, q):
         dist.destroy_process_group()
 
 
+def _run_ranks(target, world, extra_args, attempts=3):
+    """Spawn `world` gloo ranks; a rendezvous port can be taken between probing and binding, so a failed start is retried."""
+    ctx = mp.get_context("spawn")
+    for attempt in range(attempts):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port) + tuple(extra_args) + (q,)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            res = [q.get(timeout=180) for _ in procs]
+        except Exception:
+            pass
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if len(res) == world and all(p.exitcode == 0 for p in procs):
+            return res
+    raise AssertionError(f"{target.__name__}: ranks failed {attempts} times")
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -47,16 +70,7 @@ def _free_port():
 @pytest.mark.parametrize("world", [2, 3])
 def test_gather_equals_single_process(world):
     wins = tile_windows(100, 130, (20, 20), (36, 36))
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, len(wins), q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_worker, world, (len(wins),))
     for rank, ok, shape in res:
         assert ok, f"rank {rank} reassembled a different tile list"
         assert shape[0] == len(wins)
@@ -156,16 +170,7 @@ def test_sharded_cross_tile_fusion_equals_sequential_reference_semantics(world, 
     hg, wg, gp, C, tok = _ctf_case(grid)
     o = OR.CrossTileFusionOracle(mode, 2, 0.5)
     ref = torch.stack([o(tok[t:t + 1].clone(), t // wg, t % wg, gp, gp)[0] for t in range(hg * wg)], 0)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ctf_worker, args=(r, world, port, mode, grid, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_ctf_worker, world, (mode, grid))
     for rank, full in res:
         assert full.shape == ref.shape
         assert (full - ref).abs().max().item() < 1e-5, f"rank {rank}"

@@ -104,3 +104,30 @@ def test_jbu_segmentor_smoke(golden):
     with torch.no_grad():
         ref = o.forward_slide(img)
     assert (logits.cpu() - ref).abs().max().item() < 1e-3
+
+
+def test_label_and_confidence_images(golden, tmp_path):
+    """result_dir / heatmap_dir (segmentor.py:501-531): images rendered by sg_render_maps == the reference's _colorize_mask /
+    _to_colormap (its OpenCV-less branch) on the same prediction; PNG files named after the sample's img_path."""
+    from PIL import Image
+    g = golden("segment")
+    _, kw = CASES["ex_base"]
+    seg = build("SegmentorEx", torch.from_numpy(g["text"]), result_dir=str(tmp_path / "res"), heatmap_dir=str(tmp_path / "heat"), **kw)
+    assert np.array_equal(seg._generate_palette(seg.num_classes), g["viz.palette"])
+
+    class Sample:
+        def __init__(self, meta):
+            self.metainfo = meta
+
+        def set_data(self, d):
+            pass
+
+    img = torch.from_numpy(g["ex_base.img"]).cuda()
+    H, W = img.shape[-2:]
+    seg.predict(img, [Sample(dict(ori_shape=(H, W), img_path="/data/potsdam/top_2_13.tif"))])
+    mask = np.array(Image.open(tmp_path / "res" / "top_2_13.png"))
+    heat = np.array(Image.open(tmp_path / "heat" / "top_2_13.png"))
+    assert np.array_equal(mask, g["viz.mask"])
+    # the grey level is uint8(p * 255): a probability within 1e-6 of a k/255 boundary may land one level off
+    d = np.abs(heat.astype(np.int32) - g["viz.heat"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
