@@ -170,15 +170,16 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
             for (int ks = 0; ks < C::KS; ++ks)
               kf[sub][t][ks] = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
 #pragma unroll
-          for (int t = 0; t < TS; ++t)
+        for (int t = 0; t < TS; ++t)
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks)
+          for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)              // the two key sub-blocks alternate: no MFMA waits on its predecessor
               sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][t][ks], qf[t][ks], sacc[sub], 0, 0, 0);
-        }
       }
       // (b) V^T fragments of the tile are fetched NOW (transposed LDS reads, lane 4q+p of a 16-lane group addresses row q,
       // cols 4p..4p+3) so their latency hides under the softmax arithmetic below.
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
         for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
       if (do_pv) {
 #pragma unroll
-        for (int t = 0; t < C::DVT; ++t)
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
-          for (int f = 0; f < 4; ++f)
+          for (int t = 0; t < C::DVT; ++t)                 // alternate the d-blocks of O^T for the same reason
             o_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vfr[t][f]), pf[f], o_acc[t], 0, 0, 0);
       }
       if (has_next) {                                        // the other buffer was last read one iteration ago

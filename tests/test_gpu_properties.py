@@ -1,0 +1,71 @@
+"""Size-independent properties of the hot path at the bench's FULL tile size (ViT-L/14, 512 x 512 uint8 tiles, bf16), where the
+CPU oracle would take minutes: batch invariance, window-position invariance, stitch partition of unity, post-process ranges."""
+import numpy as np
+import pytest
+import torch
+
+from clip_decontamination_amd import weights as Wt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+QIDX = [0, 0, 1, 2, 3, 4, 5, 5]
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from clip_decontamination_amd.engine import HipVisionTower, HipCLIP, SimilarityEnhancementModule, OutlierSuppressionModule
+    from clip_decontamination_amd.pipeline import SegPipeline
+    cfg = Wt.vit_config("ViT-L-14")
+    tower = HipVisionTower(cfg, Wt.make_vit_weights(cfg, seed=0), precision="bf16", device=DEV)
+    tower.similarity_enhancer = SimilarityEnhancementModule(1.0, 1.0, True)
+    tower.outlier_suppressor = OutlierSuppressionModule(top_k=30)
+    text = torch.from_numpy(Wt.make_text_features(len(QIDX), cfg.embed_dim))
+    return SegPipeline(HipCLIP(tower), text, torch.tensor(QIDX), model_type="Experimental", global_debias_factor=0.2, prob_thd=0.1, bg_idx=5,
+                       apply_similarity_enhancement=True, tiles_per_launch=16)
+
+
+def test_tile_result_does_not_depend_on_its_batch_or_position(pipe):
+    """A tile's logits are a function of its pixels only: same pixels at another scene position, alone or among 11 others."""
+    scene = torch.from_numpy(Wt.make_tiles_u8(1, 1536, seed=3, smooth=True)[0]).to(DEV)          # [1536,1536,3] u8
+    wins = [(y, y + 512, x, x + 512) for y in (0, 256, 1024) for x in (0, 512, 768, 1024)]
+    all12 = pipe.tile_logits(scene, wins, (512, 512))
+    alone = pipe.tile_logits(scene, [wins[5]], (512, 512))
+    # different launch sizes may pick different GEMM tilings (summation order): bf16-level agreement, same arg-max almost everywhere
+    assert (all12[5] - alone[0]).abs().max().item() < 2e-3
+    assert (all12[5].argmax(0) == alone[0].argmax(0)).float().mean().item() > 0.995
+    # the same pixels copied to another place of the scene, same launch shape: bit-identical
+    y, x = wins[5][0], wins[5][2]
+    scene2 = scene.clone()
+    scene2[1024:1536, 0:512] = scene[y:y + 512, x:x + 512]
+    moved = pipe.tile_logits(scene2, [(1024, 1536, 0, 512)], (512, 512))
+    assert torch.equal(moved[0], alone[0])
+    # and twice the same call: deterministic
+    assert torch.equal(pipe.tile_logits(scene, [wins[5]], (512, 512)), alone)
+
+
+def test_stitch_is_a_partition_of_unity_and_postprocess_is_well_formed(pipe):
+    from clip_decontamination_amd import ops
+    from clip_decontamination_amd.pipeline import tile_windows
+    H, W = 1100, 1300                                            # ragged: the last windows are shifted back inside
+    wins = tile_windows(H, W, (256, 256), (512, 512))
+    T, Q = len(wins), len(QIDX)
+    const = torch.arange(Q, dtype=torch.float32, device=DEV).view(1, Q, 1, 1).expand(T, Q, 37, 37).contiguous() * 0.01
+    canvas = ops.stitch(const, torch.tensor(wins, dtype=torch.int32), (518, 518), (3, 3), (H, W))
+    want = torch.arange(Q, dtype=torch.float32, device=DEV).view(Q, 1, 1) * 0.01
+    assert (canvas - want).abs().max().item() < 1e-6             # overlap-add / count of a constant field is the constant
+    probs, labels = pipe.postprocess(canvas)
+    K = max(QIDX) + 1
+    assert probs.shape == (K, H, W) and labels.shape == (1, H, W) and labels.dtype == torch.int64
+    assert int(labels.min()) >= 0 and int(labels.max()) < K
+    assert float(probs.min()) >= 0.0 and float(probs.max()) <= 1.0 + 1e-6
+    # constant logits: every pixel gets the same label
+    assert (labels == labels.flatten()[0]).all()
+
+
+def test_full_scene_slide_runs_and_is_deterministic(pipe):
+    """A 1280 x 1536 uint8 scene (4 x 5 = 20 tiles of 512 at stride 256) through forward_slide twice."""
+    scene = torch.from_numpy(Wt.make_tiles_u8(1, 1536, seed=8, smooth=True)[0][:1280]).to(DEV)
+    a = pipe.forward_slide(scene, 256, 512)
+    b = pipe.forward_slide(scene, 256, 512)
+    assert a.shape == (1, len(QIDX), 1280, 1536) and torch.equal(a, b)
+    assert torch.isfinite(a).all()
