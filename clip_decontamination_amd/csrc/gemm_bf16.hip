@@ -781,6 +781,25 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
     bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias && n + 3 < a.N) bias4[j] = *reinterpret_cast<const float4*>(a.bias + n);
   }
+  // f32 output with residual: the residual of strip t + RD is requested while strip t goes through the patch, so RD strips of HBM
+  // latency are in flight per wave instead of one dependent load -> add -> store chain per strip (addresses clamped, stores guarded)
+  constexpr int RD = 4;
+  constexpr int LPRF = TN / 4, RPPF = 64 / LPRF, NPASS = 8 / RPPF;
+  float4 rbuf[RD][NPASS];
+  auto fetch_res = [&](int t, float4 (&dst)[NPASS]) {
+    const int rb = row0 + (t >> 1) * 16 + (t & 1) * 8;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      int m = rb + ps * RPPF + lane / LPRF; m = m < a.M ? m : a.M - 1;
+      int n = col0 + (lane % LPRF) * 4; n = n < a.N ? n : a.N - 4;
+      dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
+    }
+  };
+  const bool pipe_res = res != nullptr && !c_bf16;
+  if (pipe_res) {
+#pragma unroll
+    for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float4 v4[NI];
@@ -817,19 +836,20 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       } else {
         constexpr int LPR = TN / 4;
         constexpr int RPP = 64 / LPR;
+        const int t = i * 2 + hh;
 #pragma unroll
         for (int r0 = 0; r0 < 8; r0 += RPP) {
           const int r = r0 + lane / LPR, cq = (lane % LPR) * 4;
           const int m = rbase + r, n = col0 + cq;
-          if (r < 8 && m < a.M && n < a.N) {
-            float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
-            if (res) {
-              const float4 rr = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
-              x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
-            }
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = x;
+          float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          if (pipe_res) {
+            const float4 rr = rbuf[t % RD][r0 / RPP];
+            x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
           }
+          if (r < 8 && m < a.M && n < a.N)
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = x;
         }
+        if (pipe_res && t + RD < 2 * MI) fetch_res(t + RD, rbuf[t % RD]);
       }
     }
   }
