@@ -73,12 +73,22 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
   // XCD-aware order: workgroup w runs on XCD w % 8 (dispatch round-robin; used for speed only).  All query blocks of one
   // (image, head) pair are queued back to back on ONE XCD, so its K / V (350 kB at N=1370) are fetched into that XCD's L2 once
   // instead of once per query block through the fabric (rocprofv3 FETCH_SIZE: 6.1 GB -> see profiles/).
+  // With an additive bias (similarity map, shared by the H heads) the order is turned round: the H heads of one (image, query block)
+  // run back to back on one XCD, so the 128 x N bias slice (700 kB) is fetched once instead of once per head, which outweighs the
+  // K / V re-reads (bias [B,n,n] f32 is 16x the size of K and V together).
   const int nq = (a.N + QB - 1) / QB;
   const int xw = blockIdx.x & 7, jw = blockIdx.x >> 3;
-  const int grp = (jw / nq) * 8 + xw;
-  if (grp >= a.H * a.B) return;
-  const int b = grp / a.H, hd = grp % a.H;
-  const int q_glob = (jw % nq) * QB + wave * 32 + c;
+  int b, hd, qb;
+  if (GENERIC && a.bias != nullptr) {
+    const int unit = (jw / a.H) * 8 + xw;
+    if (unit >= a.B * nq) return;
+    b = unit / nq; qb = unit % nq; hd = jw % a.H;
+  } else {
+    const int grp = (jw / nq) * 8 + xw;
+    if (grp >= a.H * a.B) return;
+    b = grp / a.H; hd = grp % a.H; qb = jw % nq;
+  }
+  const int q_glob = qb * QB + wave * 32 + c;
   const int q_ld = q_glob < a.N ? q_glob : a.N - 1;
   const int n = a.N - 1;
   const float scale = a.scale_per_image ? a.scale_per_image[b] : a.scale;      // > 0
@@ -309,9 +319,10 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   auto kern = generic ? (multi ? attn_kernel<DH, TS, true, true> : attn_kernel<DH, TS, true, false>)
                       : (multi ? attn_kernel<DH, TS, false, true> : attn_kernel<DH, TS, false, false>);
   if (lds > 64 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int64_t n_grp8 = cdiv((int64_t)a.H * a.B, 8);
-  SG_REQUIRE(n_grp8 * 8 * cdiv(a.N, QB) < (1ll << 31), "attention: grid too large");
-  dim3 grid((unsigned)(n_grp8 * 8 * cdiv(a.N, QB)));
+  const int64_t nqb = cdiv(a.N, QB);
+  const int64_t nblk = (generic && a.bias) ? cdiv((int64_t)a.B * nqb, 8) * 8 * a.H : cdiv((int64_t)a.H * a.B, 8) * 8 * nqb;
+  SG_REQUIRE(nblk < (1ll << 31), "attention: grid too large");
+  dim3 grid((unsigned)nblk);
   // algorithmic FLOPs: 2*N*N*dh per (term score) + 2*N*N*dh per stream PV, per (image, head)
   const int streams = a.sum_scores ? 1 : a.n_terms;
   const double fl = (double)a.B * a.H * 2.0 * a.N * (double)a.N * DH * (a.n_terms + (a.ctx ? streams : 0));

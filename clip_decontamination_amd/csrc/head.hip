@@ -12,7 +12,8 @@
 namespace sg {
 
 // ---- cosine logits -------------------------------------------------------------------------------------------
-// One wave per token.  T (Q x E) is staged once per workgroup in LDS.
+// One wave per token at a time, CL_TPW tokens per wave.  T (Q x E) is staged once per workgroup in LDS.
+constexpr int CL_TPW = 8, CL_TPB = 4 * CL_TPW, CL_MAXV = 32;   // E <= 64 * CL_MAXV
 __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restrict__ tokens, const float* __restrict__ cls,
                                                             const float* __restrict__ text, int n, int E, int Q, float debias,
                                                             float lambda, float* __restrict__ logits) {
@@ -41,39 +42,56 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
     }
   }
   __syncthreads();
-  const int t = blockIdx.x * 4 + wave;
-  if (t >= n) return;
-  const float* f = tokens + ((int64_t)b * n + t) * E;
-  // similarity-weighted debias (:322-336): f' = f - cls * (cos(f, cls) * factor); cls already unit norm,
-  // the reference renormalises it once more (a no-op up to rounding) -- reproduced for fidelity.
-  float ff = 0.f, fc = 0.f, cc = 0.f;
-  for (int i = lane; i < E; i += 64) {
-    const float x = f[i];
-    ff += x * x;
-    if (use_cls) { fc += x * sC[i]; cc += sC[i] * sC[i]; }
-  }
-  ff = wave_sum(ff);
-  float w = 0.f;
-  if (use_cls && debias != 0.f) {
-    fc = wave_sum(fc); cc = wave_sum(cc);
-    w = (fc / (sqrtf(ff) * sqrtf(cc))) * debias;
-  }
-  float nn = 0.f;
-  for (int i = lane; i < E; i += 64) {
-    const float x = (use_cls && debias != 0.f) ? f[i] - sC[i] * w : f[i];
-    nn += x * x;
-  }
-  const float inv = 1.0f / sqrtf(wave_sum(nn));
-  for (int q = 0; q < Q; ++q) {
-    float d = 0.f;
-    for (int i = lane; i < E; i += 64) {
-      const float x = (use_cls && debias != 0.f) ? f[i] - sC[i] * w : f[i];
-      d += (x * inv) * sT[q * E + i];
+  // CL_TPW tokens per wave: the staging above (Q x E text rows, unit CLS, CLS logits) is paid once per CL_TPB tokens, and a token's
+  // features are read from HBM once and kept in registers for the three passes (norm / debias, renormalise, Q dot products).
+  // Per-lane accumulation order (i = lane, lane + 64, ...) is unchanged, so results are bit-identical to the one-token form.
+  for (int tt = 0; tt < CL_TPW; ++tt) {
+    const int t = blockIdx.x * CL_TPB + wave * CL_TPW + tt;
+    if (t >= n) break;
+    const float* f = tokens + ((int64_t)b * n + t) * E;
+    float x[CL_MAXV];
+#pragma unroll
+    for (int k = 0; k < CL_MAXV; ++k) { const int i = lane + 64 * k; x[k] = i < E ? f[i] : 0.f; }
+    // similarity-weighted debias (:322-336): f' = f - cls * (cos(f, cls) * factor); cls already unit norm,
+    // the reference renormalises it once more (a no-op up to rounding) -- reproduced for fidelity.
+    float ff = 0.f, fc = 0.f, cc = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL_MAXV; ++k) {
+      const int i = lane + 64 * k;
+      if (i < E) {
+        ff += x[k] * x[k];
+        if (use_cls) { fc += x[k] * sC[i]; cc += sC[i] * sC[i]; }
+      }
     }
-    d = wave_sum(d);
-    if (lane == 0) {
-      if (use_cls && lambda != 0.f) d += sCL[q] * lambda;
-      logits[((int64_t)b * Q + q) * n + t] = d;
+    ff = wave_sum(ff);
+    float w = 0.f;
+    const bool deb = use_cls && debias != 0.f;
+    if (deb) {
+      fc = wave_sum(fc); cc = wave_sum(cc);
+      w = (fc / (sqrtf(ff) * sqrtf(cc))) * debias;
+    }
+    float nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL_MAXV; ++k) {
+      const int i = lane + 64 * k;
+      if (i < E) {
+        if (deb) x[k] = x[k] - sC[i] * w;
+        nn += x[k] * x[k];
+      }
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(nn));
+    for (int q = 0; q < Q; ++q) {
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < CL_MAXV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < E) d += (x[k] * inv) * sT[q * E + i];
+      }
+      d = wave_sum(d);
+      if (lane == 0) {
+        if (use_cls && lambda != 0.f) d += sCL[q] * lambda;
+        logits[((int64_t)b * Q + q) * n + t] = d;
+      }
     }
   }
 }
@@ -209,8 +227,9 @@ extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const flo
   SG_REQUIRE(cls || (global_debias_factor == 0.f && cls_token_lambda == 0.f), "sg_cosine_logits: cls required for debias / lambda");
   const size_t lds = ((size_t)Q * E + E + Q) * sizeof(float);
   SG_REQUIRE(lds <= 160 * 1024, "sg_cosine_logits: Q*E=%d exceeds LDS", Q * E);
+  SG_REQUIRE(E <= 64 * CL_MAXV, "sg_cosine_logits: E=%d exceeds %d", E, 64 * CL_MAXV);
   if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_logits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(cosine_logits_kernel, dim3((unsigned)cdiv(n, 4), (unsigned)B), dim3(256), lds, as_stream(s), tokens, cls, text,
+  hipLaunchKernelGGL(cosine_logits_kernel, dim3((unsigned)cdiv(n, CL_TPB), (unsigned)B), dim3(256), lds, as_stream(s), tokens, cls, text,
                      n, E, Q, global_debias_factor, cls_token_lambda, logits);
   SG_LAUNCH_CHECK();
   return SG_OK;
