@@ -108,31 +108,76 @@ __device__ __forceinline__ void bilinear_tap(int dst, int in, int out, int& i0, 
 }
 
 // ---- stitch -------------------------------------------------------------------------------------------------------
+// Write-once: a pixel's contributions are summed in registers in raster order of the tiles (the reference's `preds[...] += `
+// order, so the f32 sum is bit-identical), divided by the count and stored a single time.  The row test of a tile is wave-uniform
+// (one canvas row per wave) and runs on the scalar unit; queries go through the registers in chunks of ST_QC.
+constexpr int ST_QC = 8, ST_MAXC = 64;
 __global__ __launch_bounds__(256) void stitch_kernel(const float* __restrict__ tile_logits, const int32_t* __restrict__ windows,
                                                      int T, int Q, int gh, int gw, int up_h, int up_w, int pad_t, int pad_l,
                                                      int H, int W, float* __restrict__ canvas) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
-  const int64_t plane = (int64_t)H * W;
-  float cnt = 0.f;
-  for (int q = 0; q < Q; ++q) canvas[q * plane + (int64_t)y * W + x] = 0.f;
-  for (int t = 0; t < T; ++t) {                                        // raster order = the reference's add order
-    const int y1 = windows[t * 4 + 0], y2 = windows[t * 4 + 1], x1 = windows[t * 4 + 2], x2 = windows[t * 4 + 3];
-    if (y < y1 || y >= y2 || x < x1 || x >= x2) continue;
-    int ya, yb, xa, xb; float wy0, wy1, wx0, wx1;
-    bilinear_tap(y - y1 + pad_t, gh, up_h, ya, yb, wy0, wy1);
-    bilinear_tap(x - x1 + pad_l, gw, up_w, xa, xb, wx0, wx1);
-    const float* base = tile_logits + (int64_t)t * Q * gh * gw;
-    for (int q = 0; q < Q; ++q) {
-      const float* p = base + (int64_t)q * gh * gw;
-      const float top = p[ya * gw + xa] * wx0 + p[ya * gw + xb] * wx1;
-      const float bot = p[yb * gw + xa] * wx0 + p[yb * gw + xb] * wx1;
-      canvas[q * plane + (int64_t)y * W + x] += top * wy0 + bot * wy1;
+  // candidate tiles of this 64 x 4 pixel block, compacted IN RASTER ORDER by wave 0 (ballot + prefix popcount): the per-pixel
+  // loop then visits the handful of overlapping tiles instead of testing all T windows
+  __shared__ int s_list[ST_MAXC];
+  __shared__ int s_count;
+  const int lane = threadIdx.x & 63;
+  const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
+  if ((threadIdx.x >> 6) == 0) {
+    int base = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      bool hit = false;
+      if (t < T) {
+        const int y1 = windows[t * 4 + 0], y2 = windows[t * 4 + 1], x1 = windows[t * 4 + 2], x2 = windows[t * 4 + 3];
+        hit = y1 < by0 + 4 && y2 > by0 && x1 < bx0 + 64 && x2 > bx0;
+      }
+      const unsigned long long m = __ballot(hit);
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && pos < ST_MAXC) s_list[pos] = t;
+      base += __popcll(m);
     }
-    cnt += 1.f;
+    if (lane == 0) s_count = base;
   }
-  if (cnt > 0.f) for (int q = 0; q < Q; ++q) canvas[q * plane + (int64_t)y * W + x] /= cnt;
+  __syncthreads();
+  const int n_cand = s_count;
+  const bool use_list = n_cand <= ST_MAXC;                         // pathological overlap (stride << crop): test every window
+  const int n_iter = use_list ? n_cand : T;
+  const int x = bx0 + lane;
+  const int y = __builtin_amdgcn_readfirstlane(by0 + (threadIdx.x >> 6));
+  if (y >= H) return;
+  const int64_t plane = (int64_t)H * W;
+  const int64_t tile_sz = (int64_t)gh * gw;
+  for (int q0 = 0; q0 < Q; q0 += ST_QC) {
+    float acc[ST_QC];
+#pragma unroll
+    for (int k = 0; k < ST_QC; ++k) acc[k] = 0.f;
+    float cnt = 0.f;
+    for (int it = 0; it < n_iter; ++it) {                              // raster order = the reference's add order
+      const int t = use_list ? s_list[it] : it;
+      const int y1 = windows[t * 4 + 0], y2 = windows[t * 4 + 1];
+      if (y < y1 || y >= y2) continue;                                 // wave-uniform: the whole wave skips the tile
+      const int x1 = windows[t * 4 + 2], x2 = windows[t * 4 + 3];
+      if (x < x1 || x >= x2 || x >= W) continue;
+      int ya, yb, xa, xb; float wy0, wy1, wx0, wx1;
+      bilinear_tap(y - y1 + pad_t, gh, up_h, ya, yb, wy0, wy1);
+      bilinear_tap(x - x1 + pad_l, gw, up_w, xa, xb, wx0, wx1);
+      const float* base = tile_logits + ((int64_t)t * Q + q0) * tile_sz;
+#pragma unroll
+      for (int k = 0; k < ST_QC; ++k) {
+        if (q0 + k < Q) {
+          const float* p = base + (int64_t)k * tile_sz;
+          const float top = p[ya * gw + xa] * wx0 + p[ya * gw + xb] * wx1;
+          const float bot = p[yb * gw + xa] * wx0 + p[yb * gw + xb] * wx1;
+          acc[k] += top * wy0 + bot * wy1;
+        }
+      }
+      cnt += 1.f;
+    }
+    if (x < W) {
+#pragma unroll
+      for (int k = 0; k < ST_QC; ++k)
+        if (q0 + k < Q) canvas[(q0 + k) * plane + (int64_t)y * W + x] = cnt > 0.f ? acc[k] / cnt : 0.f;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ src, int C, int h, int w,
@@ -153,26 +198,36 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
 
 // ---- postprocess ----------------------------------------------------------------------------------------------------
 constexpr int PP_MAX_Q = 64;
+// QMAX is a compile-time bound on Q so that v[] lives in registers (a runtime-sized v[64] goes to scratch memory)
+template <int QMAX>
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ logits, const int32_t* __restrict__ query_idx,
                                                           int Q, int K, int64_t HW, float logit_scale, float prob_thd, int bg_idx,
                                                           float* __restrict__ probs, int64_t* __restrict__ labels) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= HW) return;
-  float v[PP_MAX_Q];
+  float v[QMAX];
   float mx = -INFINITY;
-  for (int q = 0; q < Q; ++q) { v[q] = logits[q * HW + i] * logit_scale; mx = fmaxf(mx, v[q]); }
+#pragma unroll
+  for (int q = 0; q < QMAX; ++q)
+    if (q < Q) { v[q] = logits[q * HW + i] * logit_scale; mx = fmaxf(mx, v[q]); }
   float sum = 0.f;
-  for (int q = 0; q < Q; ++q) { v[q] = expf(v[q] - mx); sum += v[q]; }
+#pragma unroll
+  for (int q = 0; q < QMAX; ++q)
+    if (q < Q) { v[q] = expf(v[q] - mx); sum += v[q]; }
   float best = -INFINITY; int arg = 0;
   for (int c = 0; c < K; ++c) {
     float pc;
-    if (K == Q) pc = v[c] / sum;
-    else {
+    if (K == Q) {
+      pc = 0.f;
+#pragma unroll
+      for (int q = 0; q < QMAX; ++q) if (q == c) pc = v[q] / sum;       // static indexing keeps v[] in registers
+    } else {
       // (probabilities * one_hot).max over queries (segmentor.py:484-486): zeros take part in the max
-      pc = (Q > 0) ? 0.f : -INFINITY;
       bool any_other = false;
       float m = -INFINITY;
-      for (int q = 0; q < Q; ++q) { if (query_idx[q] == c) m = fmaxf(m, v[q] / sum); else any_other = true; }
+#pragma unroll
+      for (int q = 0; q < QMAX; ++q)
+        if (q < Q) { if (query_idx[q] == c) m = fmaxf(m, v[q] / sum); else any_other = true; }
       pc = any_other ? fmaxf(m, 0.f) : m;
     }
     if (probs) probs[c * HW + i] = pc;
@@ -259,8 +314,12 @@ extern "C" int sg_postprocess(const float* logits, const int32_t* query_idx, int
   SG_REQUIRE(logits && query_idx && labels, "sg_postprocess: null pointer");
   SG_REQUIRE(Q > 0 && Q <= PP_MAX_Q && K > 0 && K <= Q, "sg_postprocess: Q=%d K=%d unsupported (Q <= %d)", Q, K, PP_MAX_Q);
   const int64_t HW = (int64_t)H * W;
-  hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)cdiv(HW, 256)), dim3(256), 0, as_stream(s), logits, query_idx, Q, K, HW,
-                     logit_scale, prob_thd, bg_idx, probs, labels);
+  if (Q <= 16)
+    hipLaunchKernelGGL(postprocess_kernel<16>, dim3((unsigned)cdiv(HW, 256)), dim3(256), 0, as_stream(s), logits, query_idx, Q, K, HW,
+                       logit_scale, prob_thd, bg_idx, probs, labels);
+  else
+    hipLaunchKernelGGL(postprocess_kernel<PP_MAX_Q>, dim3((unsigned)cdiv(HW, 256)), dim3(256), 0, as_stream(s), logits, query_idx, Q, K, HW,
+                       logit_scale, prob_thd, bg_idx, probs, labels);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

@@ -229,9 +229,10 @@ def test_resize_bilinear(ops, src, dst):
     assert (out.cpu() - ref).abs().max().item() < 2e-6
 
 
-def test_stitch_equals_reference_loop(ops):
+@pytest.mark.parametrize("Q,H,W,crop,stride,P", [(6, 75, 60, 36, 20, 8), (11, 130, 200, 36, 20, 8),
+                                                 (3, 52, 56, 32, 2, 8)])       # last: 143 windows, > 64 overlap one block
+def test_stitch_equals_reference_loop(ops, Q, H, W, crop, stride, P):
     """Write-once stitch vs the reference's per-tile upsample / un-pad / add / count loop (segmentor.py:416-447)."""
-    Q, H, W, crop, stride, P = 6, 75, 60, 36, 20, 8
     o = OS.SegOracle.__new__(OS.SegOracle)
     o.slide_stride, o.slide_crop = stride, crop
     wins = o.tile_windows(H, W)
