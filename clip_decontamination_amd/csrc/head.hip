@@ -14,6 +14,7 @@ namespace sg {
 // ---- cosine logits -------------------------------------------------------------------------------------------
 // One wave per token at a time, CL_TPW tokens per wave.  T (Q x E) is staged once per workgroup in LDS.
 constexpr int CL_TPW = 8, CL_TPB = 4 * CL_TPW, CL_MAXV = 32;   // E <= 64 * CL_MAXV
+template <int NV>      // NV = compile-time bound on E / 64 (features of a token held in NV registers per lane)
 __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restrict__ tokens, const float* __restrict__ cls,
                                                             const float* __restrict__ text, int n, int E, int Q, float debias,
                                                             float lambda, float* __restrict__ logits) {
@@ -49,14 +50,14 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
     const int t = blockIdx.x * CL_TPB + wave * CL_TPW + tt;
     if (t >= n) break;
     const float* f = tokens + ((int64_t)b * n + t) * E;
-    float x[CL_MAXV];
+    float x[NV];
 #pragma unroll
-    for (int k = 0; k < CL_MAXV; ++k) { const int i = lane + 64 * k; x[k] = i < E ? f[i] : 0.f; }
+    for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; x[k] = i < E ? f[i] : 0.f; }
     // similarity-weighted debias (:322-336): f' = f - cls * (cos(f, cls) * factor); cls already unit norm,
     // the reference renormalises it once more (a no-op up to rounding) -- reproduced for fidelity.
     float ff = 0.f, fc = 0.f, cc = 0.f;
 #pragma unroll
-    for (int k = 0; k < CL_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int i = lane + 64 * k;
       if (i < E) {
         ff += x[k] * x[k];
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
     }
     float nn = 0.f;
 #pragma unroll
-    for (int k = 0; k < CL_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int i = lane + 64 * k;
       if (i < E) {
         if (deb) x[k] = x[k] - sC[i] * w;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
     for (int q = 0; q < Q; ++q) {
       float d = 0.f;
 #pragma unroll
-      for (int k = 0; k < CL_MAXV; ++k) {
+      for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         if (i < E) d += (x[k] * inv) * sT[q * E + i];
       }
@@ -283,8 +284,10 @@ extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const flo
   const size_t lds = ((size_t)Q * E + E + Q) * sizeof(float);
   SG_REQUIRE(lds <= 160 * 1024, "sg_cosine_logits: Q*E=%d exceeds LDS", Q * E);
   SG_REQUIRE(E <= 64 * CL_MAXV, "sg_cosine_logits: E=%d exceeds %d", E, 64 * CL_MAXV);
-  if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_logits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(cosine_logits_kernel, dim3((unsigned)cdiv(n, CL_TPB), (unsigned)B), dim3(256), lds, as_stream(s), tokens, cls, text,
+  const int nv = (E + 63) / 64;
+  auto kern = nv <= 8 ? cosine_logits_kernel<8> : (nv <= 12 ? cosine_logits_kernel<12> : (nv <= 16 ? cosine_logits_kernel<16> : cosine_logits_kernel<CL_MAXV>));
+  if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(n, CL_TPB), (unsigned)B), dim3(256), lds, as_stream(s), tokens, cls, text,
                      n, E, Q, global_debias_factor, cls_token_lambda, logits);
   SG_LAUNCH_CHECK();
   return SG_OK;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
 // X[pix][0..d2) = normalised combined kernel, X[pix][d2..d2+3) = guidance (the fixup conv's input rows).
 __global__ __launch_bounds__(256) void jbu_kernel_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int B, int H, int W,
                                                          int r, const float* __restrict__ range_temp, const float* __restrict__ sigma,
-                                                         float* __restrict__ X) {
+                                                         float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16) {
   const int lane = threadIdx.x & 63;
   const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t total = (int64_t)B * H * W;
@@ -134,6 +134,15 @@ __global__ __launch_bounds__(256) void jbu_kernel_kernel(const float* __restrict
   if (lane < d2) xr[lane] = e0 / nrm;
   if (lane + 64 < d2) xr[lane + 64] = e1 / nrm;
   if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
+  if (X16) {                                               // bf16 copy, zero-padded to ldx16 columns: the A operand of the fixup GEMM
+    bf16_t* x16 = X16 + pix * ldx16;
+    for (int t = lane; t < ldx16; t += 64) {
+      float v = 0.f;
+      if (t < d2) v = (t < 64 ? e0 : e1) / nrm;
+      else if (t < d2 + 3) v = gs[pix * 3 + (t - d2)];
+      x16[t] = f2bf(v);
+    }
+  }
 }
 
 // ---- bicubic 2x (torch.nn.Upsample(size, mode='bicubic', align_corners=False), A = -0.75) on [B,h,w,C] -> [B,oh,ow,C] ----------
@@ -149,8 +158,9 @@ __device__ __forceinline__ void cubic_taps(int dst, int in, int out, int* idx, f
 #pragma unroll
   for (int k = 0; k < 4; ++k) { const int j = i0 - 1 + k; idx[k] = j < 0 ? 0 : (j > in - 1 ? in - 1 : j); }
 }
+template <typename OutT>      // bf16_t in throughput mode: the matrix-core adaptive convolution consumes bf16 features
 __global__ __launch_bounds__(256) void jbu_bicubic_kernel(const float* __restrict__ src, int B, int h, int w, int C, int oh, int ow,
-                                                          float* __restrict__ dst) {
+                                                          OutT* __restrict__ dst) {
   const int C4 = C >> 2;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)B * oh * ow * C4) return;
@@ -171,14 +181,16 @@ __global__ __launch_bounds__(256) void jbu_bicubic_kernel(const float* __restric
     }
     acc.x += wy[a] * row.x; acc.y += wy[a] * row.y; acc.z += wy[a] * row.z; acc.w += wy[a] * row.w;
   }
-  *reinterpret_cast<float4*>(dst + ((int64_t)(b * oh + oy) * ow + ox) * C + 4 * c4) = acc;
+  OutT* o = dst + ((int64_t)(b * oh + oy) * ow + ox) * C + 4 * c4;
+  if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float4*>(o) = acc;
+  else { uint2 q; q.x = pack_bf2(acc.x, acc.y); q.y = pack_bf2(acc.z, acc.w); *reinterpret_cast<uint2*>(o) = q; }
 }
 
 // ---- adaptive convolution, channels-last, reflect padding folded into the window staging ---------------------------------------
 // Workgroup = 8x8 output pixels x 32 channels.  LDS holds the (8+2r)^2 reflect-indexed window of those 32 channels (row stride
 // 36 floats: conflict-free 16-byte reads across a row of pixels) and the 64 pixels' d*d weights (tap-major).
 constexpr int AC_T = 8, AC_CC = 32, AC_LD = 36;
-__global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const float* __restrict__ hr, const float* __restrict__ Kf, int H, int W,
+__global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const float* __restrict__ hr, const float* __restrict__ Kf, int ldk, int H, int W,
                                                                 int C, int r, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = 2 * r + 1, d2 = d * d, WT = AC_T + 2 * r;
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const float* __r
     const int pxl = i / d2, t = i % d2;                                              // coalesced along the taps of one pixel
     int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
     y = y < H ? y : H - 1; x = x < W ? x : W - 1;
-    sKw[t * 64 + pxl] = Kf[(((int64_t)b * H + y) * W + x) * d2 + t];
+    sKw[t * 64 + pxl] = Kf[(((int64_t)b * H + y) * W + x) * ldk + t];
   }
   __syncthreads();
   const int pxl = tid & 63, cg = tid >> 6, py = pxl >> 3, px = pxl & 7;
@@ -220,6 +232,100 @@ __global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const float* __r
     float* o = out + (((int64_t)b * H + y) * W + x) * C + c;
     if (c < C) *reinterpret_cast<float4*>(o) = a0;
     if (c + 4 < C) *reinterpret_cast<float4*>(o + 4) = a1;
+  }
+}
+
+// ---- adaptive convolution on the matrix cores (throughput mode) -----------------------------------------------------------------
+// For an 8 x 8 block of output pixels the d*d taps of every pixel fall inside one (8+2r)^2 window, so
+//     out[64 px, C] = F[64, WT^2] . Win[WT^2, C]       F[p, (py+i)*WT + (px+j)] = Kf[p, i*d+j], zero elsewhere
+// is a dense GEMM (37 % of F is non-zero at r = 5) that v_mfma_f32_16x16x32_bf16 runs ~20x faster than the 121-tap VALU loop.
+// LDS: F [64][KP+8] bf16, built once per pixel block (zero fill + scatter of the taps); Win^T [128 ch][KP+8] bf16 per channel chunk
+// (window positions contiguous = the MFMA K dimension), restaged for every chunk of 128 channels.  Operands are swapped so that a
+// lane owns 4 consecutive channels of one pixel (16-byte stores).  Features and kernel weights are rounded to bf16 (weights are in
+// [0,1] and sum to 1): throughput mode only, the f32 parity mode keeps the VALU kernel above.
+constexpr int ACM_CC = 128;
+__global__ __launch_bounds__(256) void jbu_adaptive_conv_mfma_kernel(const bf16_t* __restrict__ hr, const float* __restrict__ Kf, int ldk, int H,
+                                                                     int W, int C, int r, int KP, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char acm_sm[];
+  const int d = 2 * r + 1, d2 = d * d, WT = AC_T + 2 * r, NPOS = WT * WT, LDK = KP + 8;
+  bf16_t* sF = reinterpret_cast<bf16_t*>(acm_sm);            // [64][LDK]
+  bf16_t* sW = sF + 64 * LDK;                                // [ACM_CC][LDK]
+  const int tiles_x = (W + AC_T - 1) / AC_T;
+  // XCD-aware order: workgroups of one XCD (blockIdx.x % 8) walk a contiguous raster range of pixel blocks, so the halo rows /
+  // columns shared by neighbouring blocks (5x read amplification at r = 5) are served by that XCD's L2
+  const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+  const int ty0 = (blk / tiles_x) * AC_T, tx0 = (blk % tiles_x) * AC_T;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* hb = hr + (int64_t)b * H * W * C;
+  // F: zero, then scatter the taps
+  for (int i = tid; i < 64 * LDK / 8; i += 256) reinterpret_cast<uint4*>(sF)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (int i = tid; i < d2 * 64; i += 256) {
+    const int pxl = i / d2, t = i % d2;                                              // coalesced along the taps of one pixel
+    int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+    y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+    const int ti = t / d, tj = t % d;
+    sF[pxl * LDK + ((pxl >> 3) + ti) * WT + (pxl & 7) + tj] = f2bf(Kf[(((int64_t)b * H + y) * W + x) * ldk + t]);
+  }
+  for (int c0 = 0; c0 < C; c0 += ACM_CC) {
+    __syncthreads();                                         // F complete / previous chunk's MFMAs done with sW
+    // Win^T: thread = (8 channels, position pair); two neighbouring positions go out as one 32-bit word per channel
+    const int npair = KP / 2;
+    for (int i = tid; i < npair * (ACM_CC / 8); i += 256) {
+      const int q = i % (ACM_CC / 8), pp = i / (ACM_CC / 8);
+      uint4 v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pos = 2 * pp + e;
+        v[e] = make_uint4(0, 0, 0, 0);
+        if (pos < NPOS && c0 + 8 * q < C) {
+          int sy = ty0 + pos / WT - r, sx = tx0 + pos % WT - r;
+          sy = sy > H - 1 + r ? H - 1 + r : sy; sx = sx > W - 1 + r ? W - 1 + r : sx;  // ragged last tile: stay inside the padded image
+          sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
+          v[e] = *reinterpret_cast<const uint4*>(hb + ((int64_t)sy * W + sx) * C + c0 + 8 * q);
+        }
+      }
+      uint32_t* dst = reinterpret_cast<uint32_t*>(sW + (8 * q) * LDK + 2 * pp);
+      const uint32_t a[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, bq[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) {                       // word w2 holds channels 2 w2 (low half) and 2 w2 + 1 (high half)
+        dst[(2 * w2) * (LDK / 2)] = (a[w2] & 0xffffu) | (bq[w2] << 16);
+        dst[(2 * w2 + 1) * (LDK / 2)] = (a[w2] >> 16) | (bq[w2] & 0xffff0000u);
+      }
+    }
+    __syncthreads();
+    // wave w: channels [32w, 32w+32) of the chunk x all 64 pixels
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < KP; k0 += 32) {
+      bf16x8 fa[4], fw[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(sF + (mi * 16 + (lane & 15)) * LDK + k0 + (lane >> 4) * 8);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) fw[nj] = *reinterpret_cast<const bf16x8*>(sW + (wave * 32 + nj * 16 + (lane & 15)) * LDK + k0 + (lane >> 4) * 8);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nj], fa[mi], acc[mi][nj], 0, 0, 0);
+    }
+    // lane: pixel mi*16 + (lane & 15), channels c0 + 32 wave + 16 nj + 4 (lane >> 4) .. +4
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int pxl = mi * 16 + (lane & 15);
+      const int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+      if (y < H && x < W) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          const int c = c0 + wave * 32 + nj * 16 + (lane >> 4) * 4;
+          if (c < C) *reinterpret_cast<float4*>(out + (((int64_t)b * H + y) * W + x) * C + c) =
+              make_float4(acc[mi][nj][0], acc[mi][nj][1], acc[mi][nj][2], acc[mi][nj][3]);
+        }
+      }
+    }
   }
 }
 
@@ -269,7 +375,11 @@ __global__ __launch_bounds__(256) void global_debias_kernel(const float* __restr
 struct JbuStage {
   int r;
   float *range_temp, *sigma, *rp0_w, *rp0_b, *rp3_w, *rp3_b, *fx0_w, *fx0_b, *fx3_w, *fx3_b;
+  // throughput mode: the two fixup linears on the bf16 MFMA GEMM, operands zero-padded to [NP, KP1] / [NP, NP] (NP, KP1 multiples of 64)
+  void *fx0_w16, *fx3_w16; float *fx0_bp, *fx3_bp;
 };
+static inline int jbu_np(int r) { const int d = 2 * r + 1; return (int)align_up((size_t)d * d, 64); }
+static inline int jbu_kp1(int r) { const int d = 2 * r + 1; return (int)align_up((size_t)d * d + 3, 64); }
 
 }  // namespace sg
 
@@ -316,6 +426,8 @@ extern "C" int sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim) {
       JbuStage& S = j->st[s]; S.r = r;
       float** slots[10] = {&S.range_temp, &S.sigma, &S.rp0_w, &S.rp0_b, &S.rp3_w, &S.rp3_b, &S.fx0_w, &S.fx0_b, &S.fx3_w, &S.fx3_b};
       for (int t = 0; t < 10; ++t) *slots[t] = (float*)take((size_t)stage_numel(t, r) * 4);
+      S.fx0_w16 = take((size_t)jbu_np(r) * jbu_kp1(r) * 2); S.fx3_w16 = take((size_t)jbu_np(r) * jbu_np(r) * 2);
+      S.fx0_bp = (float*)take((size_t)jbu_np(r) * 4); S.fx3_bp = (float*)take((size_t)jbu_np(r) * 4);
     }
     j->fin_w = (float*)take((size_t)feat_dim * feat_dim * 4);
     j->fin_b = (float*)take((size_t)feat_dim * 4);
@@ -327,6 +439,7 @@ extern "C" int sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim) {
   hipError_t e = hipMalloc(&j->arena, bytes);
   if (e != hipSuccess) { delete j; return fail(SG_ERR_HIP, "sg_jbu_create: hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e)); }
   lay((char*)j->arena);
+  SG_HIP(hipMemset(j->arena, 0, bytes));                  // the zero padding of the bf16 fixup operands
   j->have.assign(j->n_stage_sets * 10 + 2, 0);
   *out = j;
   return SG_OK;
@@ -370,6 +483,11 @@ extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, 
           hipLaunchKernelGGL(scale_kernel, dim3((unsigned)cdiv(numel, 256)), dim3(256), 0, s, slots[t], 0.1f, numel);
           SG_LAUNCH_CHECK();
         }
+        const int d2s = (2 * S.r + 1) * (2 * S.r + 1);
+        if (t == 6) SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16, jbu_kp1(S.r), 1, s));
+        if (t == 8) SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16, jbu_np(S.r), 1, s));
+        if (t == 7) SG_HIP(hipMemcpyAsync(S.fx0_bp, slots[t], (size_t)d2s * 4, hipMemcpyDeviceToDevice, s));
+        if (t == 9) SG_HIP(hipMemcpyAsync(S.fx3_bp, slots[t], (size_t)d2s * 4, hipMemcpyDeviceToDevice, s));
         j->have[set * 10 + t] = 1;
         return SG_OK;
       }
@@ -378,7 +496,7 @@ extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, 
 }
 
 namespace sg {
-struct JbuPlan { float *gs, *proj, *X, *H1, *Kf, *hr, *bufA, *bufB; void* x16; };
+struct JbuPlan { float *gs, *proj, *X, *H1, *Kf, *hr, *bufA, *bufB; void* x16; bf16_t *X16, *H116; };
 static size_t jbu_plan(const sg_jbu* j, int B, int gh, int gw, void* ws, bool dry, JbuPlan& p) {
   const int r = j->st[0].r, d2 = (2 * r + 1) * (2 * r + 1);
   const int64_t pixels = (int64_t)B * 16 * gh * 16 * gw;              // final resolution
@@ -386,9 +504,12 @@ static size_t jbu_plan(const sg_jbu* j, int B, int gh, int gw, void* ws, bool dr
   auto take = [&](size_t n) { off = align_up(off, 256); void* q = dry ? nullptr : (char*)ws + off; off += n; return q; };
   p.gs = (float*)take((size_t)pixels * 3 * 4);
   p.proj = (float*)take((size_t)pixels * KEY_DIM * 4);
-  p.X = (float*)take((size_t)pixels * (d2 + 3) * 4);
+  const int NP = jbu_np(r), KP1 = jbu_kp1(r);
+  p.X = (float*)take((size_t)pixels * (d2 + 3) * 4 + 1024);           // + slack: the padded fixup GEMM reads its residual NP columns wide
   p.H1 = (float*)take((size_t)pixels * d2 * 4);
-  p.Kf = (float*)take((size_t)pixels * d2 * 4);
+  p.Kf = (float*)take((size_t)pixels * NP * 4);                       // row stride d2 (parity mode) or NP (throughput mode)
+  p.X16 = (bf16_t*)take((size_t)pixels * KP1 * 2);
+  p.H116 = (bf16_t*)take((size_t)pixels * NP * 2);
   p.hr = (float*)take((size_t)pixels * j->C * 4);
   p.bufA = (float*)take((size_t)pixels / 4 * j->C * 4);                // stage-3 output (8x): ping
   p.bufB = (float*)take((size_t)pixels * j->C * 4);                    // stage-2 / stage-4 output: pong
@@ -428,27 +549,53 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
     hipLaunchKernelGGL(jbu_range_proj_kernel, dim3((unsigned)cdiv(pixels, 256)), dim3(256), 0, s, p.gs, pixels, S.rp0_w, S.rp0_b, S.rp3_w,
                        S.rp3_b, p.proj);
     SG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jbu_kernel_kernel, dim3((unsigned)cdiv(pixels, 4)), dim3(256), 0, s, p.proj, p.gs, B, oh, ow, r, S.range_temp, S.sigma, p.X);
+    const bool fast = precision == SG_PREC_BF16 && C % 8 == 0;       // throughput mode: bf16 MFMA for the fixup linears and the convolution
+    const int NP = jbu_np(r), KP1 = jbu_kp1(r), ldk = fast ? NP : d2;
+    hipLaunchKernelGGL(jbu_kernel_kernel, dim3((unsigned)cdiv(pixels, 4)), dim3(256), 0, s, p.proj, p.gs, B, oh, ow, r, S.range_temp, S.sigma, p.X,
+                       fast ? p.X16 : nullptr, KP1);
     SG_LAUNCH_CHECK();
-    {  // fixup: H1 = GELU(X . W0^T + b0);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3)
+    SG_REQUIRE(pixels < (1ll << 31), "sg_jbu_upsample: too many pixels");
+    if (fast) {  // H1 = GELU(X . W0^T + b0) (bf16);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3), columns >= d2 are padding
+      GemmBf16Args g{};
+      g.A = p.X16; g.lda = KP1; g.W = (const bf16_t*)S.fx0_w16; g.ldw = KP1; g.bias = S.fx0_bp; g.C = p.H116; g.ldc = NP; g.c_is_bf16 = 1;
+      g.M = (int)pixels; g.N = NP; g.K = KP1; g.batch = 1; g.act = ACT_GELU; g.alpha = 1.f;
+      SG_TRY(gemm_bf16(g, s));
+      GemmBf16Args q{};
+      q.A = p.H116; q.lda = NP; q.W = (const bf16_t*)S.fx3_w16; q.ldw = NP; q.bias = S.fx3_bp; q.residual = p.X; q.ldr = d2 + 3;
+      q.C = p.Kf; q.ldc = NP; q.c_is_bf16 = 0; q.M = (int)pixels; q.N = NP; q.K = NP; q.batch = 1; q.act = ACT_NONE; q.alpha = 0.1f;
+      SG_TRY(gemm_bf16(q, s));
+    } else {  // fixup: H1 = GELU(X . W0^T + b0);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3)
       GemmF32Args g{};
       g.A = p.X; g.lda = d2 + 3; g.B = S.fx0_w; g.sbk = 1; g.sbn = d2 + 3; g.bias = S.fx0_b; g.C = p.H1; g.ldc = d2;
       g.M = (int)pixels; g.N = d2; g.K = d2 + 3; g.batch = 1; g.inner = 1; g.act = ACT_GELU; g.alpha = 1.f;
-      SG_REQUIRE(pixels < (1ll << 31), "sg_jbu_upsample: too many pixels");
       SG_TRY(gemm_f32(g, s));
       GemmF32Args q{};
       q.A = p.H1; q.lda = d2; q.B = S.fx3_w; q.sbk = 1; q.sbn = d2; q.bias = S.fx3_b; q.residual = p.X; q.ldr = d2 + 3; q.C = p.Kf; q.ldc = d2;
       q.M = (int)pixels; q.N = d2; q.K = d2; q.batch = 1; q.inner = 1; q.act = ACT_NONE; q.alpha = 0.1f;
       SG_TRY(gemm_f32(q, s));
     }
-    hipLaunchKernelGGL(jbu_bicubic_kernel, dim3((unsigned)cdiv(pixels * (C / 4), 256)), dim3(256), 0, s, src, B, h, w, C, oh, ow, p.hr);
+    const bool mfma_conv = fast;
+    if (mfma_conv) hipLaunchKernelGGL(jbu_bicubic_kernel<bf16_t>, dim3((unsigned)cdiv(pixels * (C / 4), 256)), dim3(256), 0, s, src, B, h, w, C, oh, ow, (bf16_t*)p.hr);
+    else hipLaunchKernelGGL(jbu_bicubic_kernel<float>, dim3((unsigned)cdiv(pixels * (C / 4), 256)), dim3(256), 0, s, src, B, h, w, C, oh, ow, p.hr);
     SG_LAUNCH_CHECK();
-    {
+    if (mfma_conv) {                                         // throughput mode: the matrix-core formulation
+      const int WT = AC_T + 2 * r, KP = (int)align_up((size_t)WT * WT, 32);
+      const size_t lds = (size_t)(64 + ACM_CC) * (KP + 8) * sizeof(bf16_t);
+      SG_REQUIRE(lds <= 160 * 1024, "sg_jbu_upsample: window %d needs %zu bytes of LDS", d, lds);
+      static bool attr_set = false;
+      if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jbu_adaptive_conv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
+      hipLaunchKernelGGL(jbu_adaptive_conv_mfma_kernel, grid, dim3(256), lds, s, (const bf16_t*)p.hr, p.Kf, ldk, oh, ow, C, r, KP, dst);
+      SG_LAUNCH_CHECK();
+    } else {
       const int WT = AC_T + 2 * r;
       const size_t lds = ((size_t)WT * WT * AC_LD + (size_t)d2 * 64) * sizeof(float);
       if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jbu_adaptive_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)cdiv(C, AC_CC), (unsigned)B);
-      hipLaunchKernelGGL(jbu_adaptive_conv_kernel, grid, dim3(256), lds, s, p.hr, p.Kf, oh, ow, C, r, dst);
+      hipLaunchKernelGGL(jbu_adaptive_conv_kernel, grid, dim3(256), lds, s, p.hr, p.Kf, ldk, oh, ow, C, r, dst);
       SG_LAUNCH_CHECK();
     }
     src = dst; h = oh; w = ow;
