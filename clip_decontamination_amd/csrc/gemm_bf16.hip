@@ -1103,6 +1103,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
       case 9: rc = launch_ring<128, 256, 1, 4, 3, 0, 32>(a, vec, s); break;    // 72 KiB LDS: two workgroups per CU
       case 10: rc = launch_ring<256, 128, 4, 1, 3, 0, 32>(a, vec, s); break;
       case 8: rc = vec ? launch_pp32<0>(a, s) : launch_pingpong(a, vec, s); break;
+#ifdef SG_GEMM_ABLATIONS                                   // tuning builds only: these variants drop loads / MFMAs / stores and return WRONG results
       case 21: rc = launch_pp32<1>(a, s); break;          // ablations of the pp32 kernel (wrong results by design)
       case 22: rc = launch_pp32<2>(a, s); break;
       case 23: rc = launch_pp32<3>(a, s); break;
@@ -1115,6 +1116,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
       case 17: rc = launch_ring<128, 128, 2, 2, 2, 3>(a, vec, s); break;
       case 18: rc = launch_ring<128, 128, 2, 2, 2, 4>(a, vec, s); break;
       case 14: rc = launch_ring<128, 128, 2, 2, 2, 2>(a, vec, s); break;
+#endif
       default: return fail(SG_ERR_INVALID, "gemm_bf16: unknown tile config %d", cfg);
     }
     prof_end(pcat, s);
