@@ -120,6 +120,16 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + h * 8);
     }
+    if (!GENERIC) {
+      // Lean path: Q is pre-multiplied by scale * log2(e) (rounded back to bf16 once per stream) and the score accumulator starts at
+      // -m_run, so the MFMA itself delivers `s * c2 - m` -- the 32 v_fma_f32 per key tile of the softmax disappear.
+#pragma unroll
+      for (int t = 0; t < TS; ++t)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qf[t][ks][j] = (__bf16)((float)qf[t][ks][j] * c2);
+    }
     // Retire the Q loads HERE: otherwise the compiler's counted vmcnt in front of the first QK^T MFMA also waits (every iteration)
     // for the K/V prefetch that was issued a few instructions earlier, exposing its full latency.
 #pragma unroll
@@ -179,10 +189,11 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks)
               kf[sub][t][ks] = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
+        const float s_init = (!GENERIC && m_run != -INFINITY) ? -m_run : 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+          for (int r = 0; r < 16; ++r) sacc[sub][r] = s_init;
 #pragma unroll
         for (int t = 0; t < TS; ++t)
 #pragma unroll
@@ -231,30 +242,52 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void 
         }
         mloc = sacc[0][0];
 #pragma unroll
-        for (int i = 1; i < 32; ++i) mloc = fmaxf(mloc, sacc[i >> 4][i & 15]);
-        mloc *= c2;                                        // c2 > 0: max commutes with the scaling
+        for (int i = 1; i < 32; ++i) mloc = fmaxf(mloc, sacc[i >> 4][i & 15]);   // already relative to the running maximum
       }
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       // Lazy online softmax: the exponentials use a STALE maximum m_run that is only raised (and the accumulators rescaled) when some
       // row's maximum has outgrown it by more than 2^RESCALE_TAU -- probabilities stay <= 2^TAU, exact in the final O / l ratio.
       // The branch is wave-uniform and, after the first tiles, almost never taken (the 32 accumulator multiplies per tile go away).
-      if (__any(mloc > m_run + RESCALE_TAU)) {
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = m_new == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
-#pragma unroll
-        for (int t = 0; t < C::DVT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
-        l_run *= alpha;
-        m_run = m_new;
-      }
-      const float m_sub = m_run == -INFINITY ? 0.f : m_run;   // a row with nothing unmasked yet: exp2(-inf - 0) = 0, never inf - inf
       float lsum = 0.f;
+      if (GENERIC) {
+        if (__any(mloc > m_run + RESCALE_TAU)) {
+          const float m_new = fmaxf(m_run, mloc);
+          const float alpha = m_new == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const float x = GENERIC ? sc[i] - m_sub : fmaf(sacc[i >> 4][i & 15], c2, -m_sub);
-        sc[i] = __builtin_amdgcn_exp2f(x);
-        lsum += sc[i];
+          for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+          l_run *= alpha;
+          m_run = m_new;
+        }
+        const float m_sub = m_run == -INFINITY ? 0.f : m_run;   // a row with nothing unmasked yet: exp2(-inf - 0) = 0, never inf - inf
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          sc[i] = __builtin_amdgcn_exp2f(sc[i] - m_sub);
+          lsum += sc[i];
+        }
+      } else {
+        // mloc is the tile maximum RELATIVE to m_run (absolute while m_run is still -inf, where the accumulator started at 0)
+        if (__any(mloc > RESCALE_TAU || m_run == -INFINITY)) {
+          const bool first = m_run == -INFINITY;
+          const float delta = first ? mloc : fmaxf(mloc, 0.f);               // how far the running maximum moves up
+          const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+          if (delta != -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sacc[i >> 4][i & 15] -= delta;
+            m_run = first ? delta : m_run + delta;
+          }
+#pragma unroll
+          for (int t = 0; t < C::DVT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+          l_run *= alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          sc[i] = __builtin_amdgcn_exp2f(sacc[i >> 4][i & 15]);
+          lsum += sc[i];
+        }
       }
       lsum += __shfl_xor(lsum, 32, 64);
       l_run += lsum;
