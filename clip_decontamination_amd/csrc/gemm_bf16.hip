@@ -855,10 +855,6 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
   }
 }
 
-// PLACE = 1 (experiment): both groups issue the 4 pieces of K tile s+3 INSIDE their MFMA(s) segment, one piece after every second
-// MFMA row (an LDS-DMA piece costs ~60 issue cycles among MFMAs, 100-185 in a READ segment, MI355X_MICROARCH.md), and the READ
-// segment shrinks to the 12 ds_read_b128.  Flight: g0 issues at slot 2s+1, g1 at 2s+2; first read of tile s+3 at slot 2s+6.
-template <int PLACE>
 __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act, int c_bf16) {
   constexpr int PBM = 256, PBN = 256, KT32 = 32;
   constexpr int TILE_B = (PBM + PBN) * KT32 * 2;             // 32 KiB per ring slot
@@ -922,19 +918,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
     for (int p = 0; p < 2; ++p)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sp.w[p] + kt * KT32), (lds_ptr_t)(base + w_dst[p]), 16, 0, 0);
   };
-  auto load_piece = [&](int u, int which, int p) {             // one 1-KiB piece: which 0 = A, 1 = W
-    if (u >= total) return;
-    const Src& sp = u >= cur_end ? nxt : cur;
-    const int kt = u >= cur_end ? u - cur_end : u - (cur_end - nt);
-    char* base = lds + (u & 3) * TILE_B;
-    if (which == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sp.a[p] + kt * KT32), (lds_ptr_t)(base + a_dst[p]), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sp.w[p] + kt * KT32), (lds_ptr_t)(base + w_dst[p]), 16, 0, 0);
-  };
-  // PLACE 1: retire everything older than the `younger` newest K tiles this wave has issued (4 pieces each)
-  auto wait_keep = [&](int u_retire, int max_younger) {
-    int y = total - 1 - u_retire; y = y < max_younger ? y : max_younger;
-    if (y >= 2) wait_vmcnt<8>(); else if (y == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
-  };
   // retire this wave's pieces of K tile u, leaving younger pieces in flight
   auto wait_tile = [&](int u) {
     if (g == 0) { if (u + 2 < total) wait_vmcnt<6>(); else if (u + 1 < total) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
@@ -949,8 +932,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 
   // prologue (group 0 holds W(2) back: it is issued in READ(0) as W(s+2))
   load_a(0); load_w(0); load_a(1); load_w(1); load_a(2);
-  if (PLACE == 1 || g == 1) load_w(2);
-  if (PLACE == 1) wait_keep(0, 2); else wait_tile(0);
+  if (g == 1) load_w(2);
+  wait_tile(0);
   SG_PS_SYNC();
   if (g == 1) SG_PS_SYNC();
 
@@ -970,28 +953,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
       for (int jj = 0; jj < 4; ++jj) fw[jj] = read_frag32(tW, 64 * wi + 16 * jj + (lane & 15), lane >> 4);
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = read_frag32(tA, 128 * g + 16 * i + (lane & 15), lane >> 4);
-      if (PLACE == 0) {
-        if (g == 0) { load_w(s + 2); load_a(s + 3); }
-        else { load_a(s + 3); load_w(s + 3); wait_tile(s + 1); }
-      } else if (g == 1) {
-        wait_keep(s + 1, 1);                                  // g1 has issued up to tile s+2 here
-      }
+      if (g == 0) { load_w(s + 2); load_a(s + 3); }
+      else { load_a(s + 3); load_w(s + 3); wait_tile(s + 1); }
       SG_PS_SYNC();
       // MFMA(s)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[jj], fa[i], acc[i][jj], 0, 0, 0);
-        if (PLACE == 1 && (i & 1)) {
-          __builtin_amdgcn_sched_barrier(0);
-          load_piece(s + 3, i >> 2, (i >> 1) & 1);            // rows 1,3 -> A pieces 0,1; rows 5,7 -> W pieces 0,1
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
       __builtin_amdgcn_s_setprio(0);
-      if (PLACE == 0) { if (g == 0) wait_tile(s + 1); }
-      else if (g == 0) wait_keep(s + 1, 2);                   // g0 has issued up to tile s+3 here
+      if (g == 0) wait_tile(s + 1);
       SG_PS_SYNC();
     }
     // ---- tile end ----
@@ -1008,13 +980,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 #undef SG_PS_SYNC
 }
 
-static int launch_persist(const GemmBf16Args& a, hipStream_t s, int place = 0) {
+static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
-    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_persist<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_persist<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     attr_set = true;
@@ -1022,8 +993,7 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s, int place = 0) {
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
-  if (place == 1) hipLaunchKernelGGL(gemm_bf16_persist<1>, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
-  else hipLaunchKernelGGL(gemm_bf16_persist<0>, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
+  hipLaunchKernelGGL(gemm_bf16_persist, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
   return SG_OK;
 }
 
@@ -1087,7 +1057,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   int cfg = g_gemm_config;
   if (cfg < 0) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups)
   if (cfg > 0) {
-    const int pcat = ((cfg == 30 || cfg == 31) && vec && a.K / 32 >= 4) ? PROF_GEMM_PERSIST : PROF_GEMM_BF16;
+    const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? PROF_GEMM_PERSIST : PROF_GEMM_BF16;
     prof_begin(pcat, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
     int rc;
     switch (cfg) {
@@ -1099,7 +1069,6 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
       case 6: rc = launch_ring<128, 256, 2, 4, 3>(a, vec, s); break;
       case 7: rc = launch_pingpong(a, vec, s); break;
       case 30: rc = (vec && a.K / 32 >= 4) ? launch_persist(a, s) : launch_pingpong(a, vec, s); break;
-      case 31: rc = (vec && a.K / 32 >= 4) ? launch_persist(a, s, 1) : launch_pingpong(a, vec, s); break;
       case 9: rc = launch_ring<128, 256, 1, 4, 3, 0, 32>(a, vec, s); break;    // 72 KiB LDS: two workgroups per CU
       case 10: rc = launch_ring<256, 128, 4, 1, 3, 0, 32>(a, vec, s); break;
       case 8: rc = vec ? launch_pp32<0>(a, s) : launch_pingpong(a, vec, s); break;
