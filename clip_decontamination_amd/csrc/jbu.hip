@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const float* __r
 // [0,1] and sum to 1): throughput mode only, the f32 parity mode keeps the VALU kernel above.
 constexpr int ACM_CC = 128;
 __global__ __launch_bounds__(256) void jbu_adaptive_conv_mfma_kernel(const bf16_t* __restrict__ hr, const float* __restrict__ Kf, int ldk, int H,
-                                                                     int W, int C, int r, int KP, float* __restrict__ out) {
+                                                                     int W, int C, int r, int KP, float* __restrict__ out, bf16_t* __restrict__ out16) {
   extern __shared__ __attribute__((aligned(16))) char acm_sm[];
   const int d = 2 * r + 1, d2 = d * d, WT = AC_T + 2 * r, NPOS = WT * WT, LDK = KP + 8;
   bf16_t* sF = reinterpret_cast<bf16_t*>(acm_sm);            // [64][LDK]
@@ -321,8 +321,14 @@ __global__ __launch_bounds__(256) void jbu_adaptive_conv_mfma_kernel(const bf16_
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
           const int c = c0 + wave * 32 + nj * 16 + (lane >> 4) * 4;
-          if (c < C) *reinterpret_cast<float4*>(out + (((int64_t)b * H + y) * W + x) * C + c) =
-              make_float4(acc[mi][nj][0], acc[mi][nj][1], acc[mi][nj][2], acc[mi][nj][3]);
+          if (c < C) {
+            const int64_t o = (((int64_t)b * H + y) * W + x) * C + c;
+            *reinterpret_cast<float4*>(out + o) = make_float4(acc[mi][nj][0], acc[mi][nj][1], acc[mi][nj][2], acc[mi][nj][3]);
+            if (out16) {                                     // last stage: the bf16 A operand of the final 1x1 conv, no separate pack pass
+              uint2 q; q.x = pack_bf2(acc[mi][nj][0], acc[mi][nj][1]); q.y = pack_bf2(acc[mi][nj][2], acc[mi][nj][3]);
+              *reinterpret_cast<uint2*>(out16 + o) = q;
+            }
+          }
         }
       }
     }
@@ -588,7 +594,8 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
         attr_set = true;
       }
       dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
-      hipLaunchKernelGGL(jbu_adaptive_conv_mfma_kernel, grid, dim3(256), lds, s, (const bf16_t*)p.hr, p.Kf, ldk, oh, ow, C, r, KP, dst);
+      hipLaunchKernelGGL(jbu_adaptive_conv_mfma_kernel, grid, dim3(256), lds, s, (const bf16_t*)p.hr, p.Kf, ldk, oh, ow, C, r, KP, dst,
+                         (stg == 3 && C % 64 == 0) ? (bf16_t*)p.x16 : nullptr);
       SG_LAUNCH_CHECK();
     } else {
       const int WT = AC_T + 2 * r;
@@ -603,7 +610,7 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
   // out = x + 0.1 * (x . Wf^T + bf)     (bias pre-scaled by 0.1 at load)
   const int64_t pixels = (int64_t)B * h * w;
   if (precision == SG_PREC_BF16 && C % 64 == 0) {
-    SG_TRY(pack_rows(src, pixels, C, C, p.x16, C, 1, s));
+    if (C % 8 != 0) SG_TRY(pack_rows(src, pixels, C, C, p.x16, C, 1, s));    // (C % 64 == 0 implies the matrix-core conv wrote x16 already)
     GemmBf16Args g{};
     g.A = (const bf16_t*)p.x16; g.lda = C; g.W = (const bf16_t*)j->fin_w16; g.ldw = C; g.bias = j->fin_b; g.residual = src; g.ldr = C;
     g.C = out; g.ldc = C; g.c_is_bf16 = 0; g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.act = 0; g.alpha = 0.1f;
