@@ -421,9 +421,62 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(const T* __restrict__ q
   }
 }
 
+// Fast form for bf16 and head_dim 32 / 64 / 128: a lane owns 8 consecutive channels (one 16-byte load) of q[0], q[j], k[j]; the LPH = dh/8
+// lanes of a head reduce with log2(LPH) shuffles, one pass over the row handles 64/LPH heads at once (the generic kernel above does
+// two 6-step wave reductions per head).
+template <int LPH>
+__global__ __launch_bounds__(256) void attn_stats_fast_kernel(const bf16_t* __restrict__ qkv, int64_t sb, int64_t st, const float* __restrict__ lse,
+                                                              int N, int H, float scale, float* __restrict__ attn_cls, float* __restrict__ attn_diag) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  const int D = H * LPH * 8;
+  const bf16_t* q0 = qkv + (int64_t)b * sb;
+  const bf16_t* qj = q0 + (int64_t)j * st;
+  const bf16_t* kj = qj + D;
+  float pc = 0.f, pd = 0.f;
+  for (int c0 = 0; c0 < D / 8; c0 += 64) {
+    const int ch = c0 + lane;                               // 8-channel chunk; head = ch / LPH
+    float dc = 0.f, dd = 0.f;
+    if (ch < D / 8) {
+      const uint4 a = *reinterpret_cast<const uint4*>(q0 + ch * 8), bq = *reinterpret_cast<const uint4*>(qj + ch * 8),
+                  kk = *reinterpret_cast<const uint4*>(kj + ch * 8);
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w}, kw[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float k0 = __uint_as_float(kw[e] << 16), k1 = __uint_as_float(kw[e] & 0xffff0000u);
+        dc += __uint_as_float(aw[e] << 16) * k0 + __uint_as_float(aw[e] & 0xffff0000u) * k1;
+        dd += __uint_as_float(bw[e] << 16) * k0 + __uint_as_float(bw[e] & 0xffff0000u) * k1;
+      }
+    }
+#pragma unroll
+    for (int o = LPH / 2; o > 0; o >>= 1) { dc += __shfl_xor(dc, o, 64); dd += __shfl_xor(dd, o, 64); }
+    if (ch < D / 8 && (lane % LPH) == 0) {
+      const int hd = ch / LPH;
+      const float* l = lse + ((int64_t)b * H + hd) * N;
+      pc += expf(dc * scale - l[0]);
+      pd += expf(dd * scale - l[j]);
+    }
+  }
+  pc = wave_sum(pc); pd = wave_sum(pd);
+  if (lane == 0) {
+    attn_cls[(int64_t)b * N + j] = pc / (float)H;
+    attn_diag[(int64_t)b * N + j] = pd / (float)H;
+  }
+}
+
 int attention_stats(const void* qkv, int is_bf16, int64_t sb, int64_t st, const float* lse, int B, int N, int H, int dh,
                     float scale, float* attn_cls, float* attn_diag, hipStream_t s) {
   dim3 grid((unsigned)cdiv(N, 4), (unsigned)B);
+  const bool aligned = (sb % 8 == 0) && (st % 8 == 0) && ((((uintptr_t)qkv) & 15) == 0);
+  if (is_bf16 && aligned && (dh == 32 || dh == 64 || dh == 128)) {
+    if (dh == 32) hipLaunchKernelGGL(attn_stats_fast_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag);
+    else if (dh == 64) hipLaunchKernelGGL(attn_stats_fast_kernel<8>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag);
+    else hipLaunchKernelGGL(attn_stats_fast_kernel<16>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+  }
   if (is_bf16) hipLaunchKernelGGL(attn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
   else hipLaunchKernelGGL(attn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
   SG_LAUNCH_CHECK();

@@ -130,10 +130,13 @@ __global__ __launch_bounds__(256) void refine_scatter_kernel(float* __restrict__
   const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int32_t* id = idx + (int64_t)b * k;
   int target, src_row;
+  if (tid == 0) s_skip = 0;
+  __syncthreads();
+  // the "who writes this cell last" test runs one candidate per thread (it was a serial loop of up to 8k iterations on thread 0)
   if (p < k) {                                           // replacement of outlier p: always written
     target = id[p]; src_row = p * 9;
     // duplicates cannot occur in a top-k; if they did, the LAST index wins (advanced-index assignment order)
-    if (tid == 0) { int skip = 0; for (int q = p + 1; q < k; ++q) if (id[q] == target) skip = 1; s_skip = skip; }
+    for (int q = p + 1 + tid; q < k; q += 256) if (id[q] == target) s_skip = 1;
   } else {
     if (!decontaminate) return;
     const int pp = p - k, i = pp >> 3, j = pp & 7;
@@ -142,18 +145,15 @@ __global__ __launch_bounds__(256) void refine_scatter_kernel(float* __restrict__
     ny = ny < 0 ? 0 : (ny > gh - 1 ? gh - 1 : ny);
     nx = nx < 0 ? 0 : (nx > gw - 1 ? gw - 1 : nx);
     target = ny * gw + nx; src_row = i * 9 + 1 + j;
-    if (tid == 0) {
-      int skip = (target == cell);                       // clamped onto the outlier itself
-      for (int q = 0; q < k && !skip; ++q) if (id[q] == target) skip = 1;       // an outlier cell: replacement wins
-      for (int q = pp + 1; q < k * 8 && !skip; ++q) {    // a later pair targets the same cell
-        const int qi = q >> 3, qj = q & 7;
-        const int qc = id[qi], qy = qc / gw, qx = qc % gw;
-        int y = qy + c_dy[qj], x = qx + c_dx[qj];
-        y = y < 0 ? 0 : (y > gh - 1 ? gh - 1 : y);
-        x = x < 0 ? 0 : (x > gw - 1 ? gw - 1 : x);
-        if (y * gw + x == target && (y * gw + x) != qc) skip = 1;
-      }
-      s_skip = skip;
+    if (tid == 0 && target == cell) s_skip = 1;            // clamped onto the outlier itself
+    for (int q = tid; q < k; q += 256) if (id[q] == target) s_skip = 1;          // an outlier cell: replacement wins
+    for (int q = pp + 1 + tid; q < k * 8; q += 256) {      // a later pair targets the same cell
+      const int qi = q >> 3, qj = q & 7;
+      const int qc = id[qi], qy = qc / gw, qx = qc % gw;
+      int y = qy + c_dy[qj], x = qx + c_dx[qj];
+      y = y < 0 ? 0 : (y > gh - 1 ? gh - 1 : y);
+      x = x < 0 ? 0 : (x > gw - 1 ? gw - 1 : x);
+      if (y * gw + x == target && (y * gw + x) != qc) s_skip = 1;
     }
   }
   __syncthreads();
