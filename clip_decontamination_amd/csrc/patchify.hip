@@ -10,9 +10,12 @@ namespace sg {
 __constant__ float c_mean[3] = {122.771f, 116.746f, 104.094f};
 __constant__ float c_std[3] = {68.501f, 66.632f, 70.323f};
 
-template <typename OutT>
-__global__ __launch_bounds__(256) void patchify_kernel(sg_tile_batch t, int P, OutT* __restrict__ out, int Kpad) {
+// PC = compile-time patch size (0 = runtime): the three index divisions per element become multiply-shifts for the shipped 14 / 16 / 32
+template <typename OutT, int PC>
+__global__ __launch_bounds__(256) void patchify_kernel(sg_tile_batch t, int P_rt, OutT* __restrict__ out, int Kpad_rt) {
   // one workgroup per (tile, patch row); threads sweep (patch col, k) with k fastest
+  const int P = PC ? PC : P_rt;
+  const int Kpad = PC ? (3 * PC * PC + 63) / 64 * 64 : Kpad_rt;
   const int tile = blockIdx.y, py_idx = blockIdx.x;
   const int y1 = t.windows[tile * 4 + 0], x1 = t.windows[tile * 4 + 2];
   const int P2 = P * P, K = 3 * P2;
@@ -45,8 +48,12 @@ int patchify(const sg_tile_batch& t, int P, void* out, int Kpad, int out_bf16, h
   SG_REQUIRE(t.grid_h * P >= t.tile_h + t.pad_t && t.grid_w * P >= t.tile_w + t.pad_l, "patchify: grid does not cover the padded tile");
   SG_REQUIRE(t.n_tiles < 65536, "patchify: too many tiles in one launch");
   dim3 grid((unsigned)t.grid_h, (unsigned)t.n_tiles);
-  if (out_bf16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
-  else hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(256), 0, s, t, P, (float*)out, Kpad);
+  const bool std_pad = Kpad == (3 * P * P + 63) / 64 * 64;
+  if (out_bf16 && std_pad && P == 14) hipLaunchKernelGGL((patchify_kernel<bf16_t, 14>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
+  else if (out_bf16 && std_pad && P == 16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 16>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
+  else if (out_bf16 && std_pad && P == 32) hipLaunchKernelGGL((patchify_kernel<bf16_t, 32>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
+  else if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 0>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
+  else hipLaunchKernelGGL((patchify_kernel<float, 0>), grid, dim3(256), 0, s, t, P, (float*)out, Kpad);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }
