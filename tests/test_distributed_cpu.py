@@ -156,7 +156,7 @@ def _ctf_worker(rank, world, port, mode, grid, q):
         steps = TorchCrossTileSteps(gp, gp, C, 2, mode, 0.5, wg)
         mine = sharded_cross_tile_fusion(tok[lo:hi].clone(), steps, T, world, rank)
         full = gather_blocks(mine, T, world, rank)
-        q.put((rank, full))
+        q.put((rank, full.numpy()))                    # by value (tensors travel as shared-memory fds that die with the child)
     finally:
         dist.destroy_process_group()
 
@@ -172,5 +172,6 @@ def test_sharded_cross_tile_fusion_equals_sequential_reference_semantics(world, 
     ref = torch.stack([o(tok[t:t + 1].clone(), t // wg, t % wg, gp, gp)[0] for t in range(hg * wg)], 0)
     res = _run_ranks(_ctf_worker, world, (mode, grid))
     for rank, full in res:
+        full = torch.from_numpy(full)
         assert full.shape == ref.shape
         assert (full - ref).abs().max().item() < 1e-5, f"rank {rank}"
