@@ -12,7 +12,7 @@
 namespace sg {
 
 // ---- cosine logits -------------------------------------------------------------------------------------------
-// One wave per token at a time, CL_TPW tokens per wave.  T (Q x E) is staged once per workgroup in LDS.
+// 16 lanes per token, four tokens per wave at a time, CL_TPW tokens per wave.  T (Q x E) is staged once per workgroup in LDS.
 constexpr int CL_TPW = 8, CL_TPB = 4 * CL_TPW, CL_MAXV = 32;   // E <= 64 * CL_MAXV
 template <int NV>      // NV = compile-time bound on E / 64 (features of a token held in NV registers per lane)
 __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restrict__ tokens, const float* __restrict__ cls,
@@ -43,53 +43,73 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
     }
   }
   __syncthreads();
-  // CL_TPW tokens per wave: the staging above (Q x E text rows, unit CLS, CLS logits) is paid once per CL_TPB tokens, and a token's
-  // features are read from HBM once and kept in registers for the three passes (norm / debias, renormalise, Q dot products).
-  // Per-lane accumulation order (i = lane, lane + 64, ...) is unchanged, so results are bit-identical to the one-token form.
-  for (int tt = 0; tt < CL_TPW; ++tt) {
-    const int t = blockIdx.x * CL_TPB + wave * CL_TPW + tt;
-    if (t >= n) break;
-    const float* f = tokens + ((int64_t)b * n + t) * E;
-    float x[NV];
+  // Four tokens per wave at a time (16 lanes each, CL_TPW tokens per wave in all): the staging above is paid once per CL_TPB tokens,
+  // a token's features are read from HBM once (one float4 per lane per 64 channels) and kept in registers for the three passes
+  // (norm / debias, renormalise, Q dot products), and every reduction is a 4-step shuffle inside the 16-lane group instead of a
+  // 6-step wave reduction per token.
+  const int sub = lane >> 4, sl = lane & 15;
+  auto group_sum = [](float v) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; x[k] = i < E ? f[i] : 0.f; }
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  const bool deb = use_cls && debias != 0.f;
+  for (int tt = 0; tt < CL_TPW; tt += 4) {
+    const int t = blockIdx.x * CL_TPB + wave * CL_TPW + tt + sub;
+    if (blockIdx.x * CL_TPB + wave * CL_TPW + tt >= n) break;             // wave-uniform: none of the four tokens exists
+    const float* f = tokens + ((int64_t)b * n + (t < n ? t : n - 1)) * E;
+    float4 x[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = 4 * sl + 64 * k;
+      x[k] = i < E ? *reinterpret_cast<const float4*>(f + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // similarity-weighted debias (:322-336): f' = f - cls * (cos(f, cls) * factor); cls already unit norm,
     // the reference renormalises it once more (a no-op up to rounding) -- reproduced for fidelity.
     float ff = 0.f, fc = 0.f, cc = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int i = lane + 64 * k;
+      const int i = 4 * sl + 64 * k;
       if (i < E) {
-        ff += x[k] * x[k];
-        if (use_cls) { fc += x[k] * sC[i]; cc += sC[i] * sC[i]; }
+        ff += (x[k].x * x[k].x + x[k].y * x[k].y) + (x[k].z * x[k].z + x[k].w * x[k].w);
+        if (use_cls) {
+          const float4 c4 = *reinterpret_cast<const float4*>(sC + i);
+          fc += (x[k].x * c4.x + x[k].y * c4.y) + (x[k].z * c4.z + x[k].w * c4.w);
+          cc += (c4.x * c4.x + c4.y * c4.y) + (c4.z * c4.z + c4.w * c4.w);
+        }
       }
     }
-    ff = wave_sum(ff);
+    ff = group_sum(ff);
     float w = 0.f;
-    const bool deb = use_cls && debias != 0.f;
     if (deb) {
-      fc = wave_sum(fc); cc = wave_sum(cc);
+      fc = group_sum(fc); cc = group_sum(cc);
       w = (fc / (sqrtf(ff) * sqrtf(cc))) * debias;
     }
     float nn = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int i = lane + 64 * k;
+      const int i = 4 * sl + 64 * k;
       if (i < E) {
-        if (deb) x[k] = x[k] - sC[i] * w;
-        nn += x[k] * x[k];
+        if (deb) {
+          const float4 c4 = *reinterpret_cast<const float4*>(sC + i);
+          x[k].x -= c4.x * w; x[k].y -= c4.y * w; x[k].z -= c4.z * w; x[k].w -= c4.w * w;
+        }
+        nn += (x[k].x * x[k].x + x[k].y * x[k].y) + (x[k].z * x[k].z + x[k].w * x[k].w);
       }
     }
-    const float inv = 1.0f / sqrtf(wave_sum(nn));
+    const float inv = 1.0f / sqrtf(group_sum(nn));
     for (int q = 0; q < Q; ++q) {
       float d = 0.f;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
-        const int i = lane + 64 * k;
-        if (i < E) d += (x[k] * inv) * sT[q * E + i];
+        const int i = 4 * sl + 64 * k;
+        if (i < E) {
+          const float4 t4 = *reinterpret_cast<const float4*>(sT + q * E + i);
+          d += ((x[k].x * inv) * t4.x + (x[k].y * inv) * t4.y) + ((x[k].z * inv) * t4.z + (x[k].w * inv) * t4.w);
+        }
       }
-      d = wave_sum(d);
-      if (lane == 0) {
+      d = group_sum(d);
+      if (sl == 0 && t < n) {
         if (use_cls && lambda != 0.f) d += sCL[q] * lambda;
         logits[((int64_t)b * Q + q) * n + t] = d;
       }
@@ -283,7 +303,8 @@ extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const flo
   SG_REQUIRE(cls || (global_debias_factor == 0.f && cls_token_lambda == 0.f), "sg_cosine_logits: cls required for debias / lambda");
   const size_t lds = ((size_t)Q * E + E + Q) * sizeof(float);
   SG_REQUIRE(lds <= 160 * 1024, "sg_cosine_logits: Q*E=%d exceeds LDS", Q * E);
-  SG_REQUIRE(E <= 64 * CL_MAXV, "sg_cosine_logits: E=%d exceeds %d", E, 64 * CL_MAXV);
+  SG_REQUIRE(E <= 64 * CL_MAXV && E % 4 == 0, "sg_cosine_logits: E=%d must be a multiple of 4 and <= %d", E, 64 * CL_MAXV);
+  SG_REQUIRE((((uintptr_t)tokens) & 15) == 0, "sg_cosine_logits: tokens must be 16-byte aligned");
   const int nv = (E + 63) / 64;
   auto kern = nv <= 8 ? cosine_logits_kernel<8> : (nv <= 12 ? cosine_logits_kernel<12> : (nv <= 16 ? cosine_logits_kernel<16> : cosine_logits_kernel<CL_MAXV>));
   if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
