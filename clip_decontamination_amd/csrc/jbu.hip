@@ -19,6 +19,7 @@
 namespace sg {
 
 constexpr int KEY_DIM = 32;
+constexpr int AC_T = 8;                 // side of the pixel block the windowed kernels (range kernel, adaptive conv) work on
 
 __device__ __forceinline__ int reflect_idx(int u, int size) {       // F.pad(mode='reflect'), pad < size
   if (u < 0) u = -u;
@@ -87,60 +88,84 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
   }
 }
 
-// ---- range * spatial kernel (upsamplers.py:230-262): one wave per pixel, the d*d taps on the lanes ---------------------------
+// ---- range * spatial kernel (upsamplers.py:230-262): the d*d taps of a pixel on the lanes of a wave -----------------------------
 // X[pix][0..d2) = normalised combined kernel, X[pix][d2..d2+3) = guidance (the fixup conv's input rows).
-__global__ __launch_bounds__(256) void jbu_kernel_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int B, int H, int W,
-                                                         int r, const float* __restrict__ range_temp, const float* __restrict__ sigma,
-                                                         float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16) {
-  const int lane = threadIdx.x & 63;
-  const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t total = (int64_t)B * H * W;
-  if (pix >= total) return;
-  const int d = 2 * r + 1, d2 = d * d, ldx = d2 + 3;
-  const int x = (int)(pix % W), y = (int)((pix / W) % H);
-  const int64_t img = (pix / W / H) * (int64_t)H * W;
+// A workgroup owns 8 x 8 pixels and stages the (8+2r)^2 window
+// of projected guidance vectors once (41 kB at r = 5) instead of fetching 121 x 128 B per pixel through L1/L2; a wave then walks its
+// 16 pixels with the d*d taps on the lanes, reading centre and neighbour vectors from LDS (row stride 36 floats: conflict-free b128).
+constexpr int JK_LD = KEY_DIM + 4;
+__global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int H, int W, int r,
+                                                               const float* __restrict__ range_temp, const float* __restrict__ sigma,
+                                                               float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16) {
+  extern __shared__ __attribute__((aligned(16))) float jk_sm[];
+  const int d = 2 * r + 1, d2 = d * d, ldx = d2 + 3, WT = AC_T + 2 * r;
+  const int tiles_x = (W + AC_T - 1) / AC_T;
+  const int ty0 = (blockIdx.x / tiles_x) * AC_T, tx0 = (blockIdx.x % tiles_x) * AC_T;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t img = (int64_t)b * H * W;
+  for (int i = tid; i < WT * WT * (KEY_DIM / 4); i += 256) {
+    const int pos = i / (KEY_DIM / 4), q = i % (KEY_DIM / 4);
+    int sy = ty0 + pos / WT - r, sx = tx0 + pos % WT - r;
+    sy = sy > H - 1 + r ? H - 1 + r : sy; sx = sx > W - 1 + r ? W - 1 + r : sx;      // ragged last tile: stay inside the padded image
+    sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
+    *reinterpret_cast<float4*>(jk_sm + pos * JK_LD + 4 * q) = *reinterpret_cast<const float4*>(proj + (img + (int64_t)sy * W + sx) * KEY_DIM + 4 * q);
+  }
+  __syncthreads();
   const float temp = fminf(fmaxf(expf(range_temp[0]), 1e-4f), 1e4f);
   const float sg = sigma[0];
   const float step = 2.0f / (float)(d - 1);
-  float4 cq[KEY_DIM / 4];
+  // tap geometry of this lane (two taps per lane), independent of the pixel
+  int toff[2]; float sp[2]; bool tv[2];
 #pragma unroll
-  for (int k = 0; k < KEY_DIM / 4; ++k) cq[k] = *reinterpret_cast<const float4*>(proj + pix * KEY_DIM + 4 * k);
-  float val[2], sp[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int t = lane + 64 * s;
-    val[s] = -INFINITY; sp[s] = 0.f;
-    if (t < d2) {
-      const int i = t / d, j = t % d;
-      const int ny = reflect_idx(y + i - r, H), nx = reflect_idx(x + j - r, W);
-      const float* q = proj + (img + (int64_t)ny * W + nx) * KEY_DIM;
-      float dot = 0.f;
-#pragma unroll
-      for (int k = 0; k < KEY_DIM / 4; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(q + 4 * k);
-        dot += v.x * cq[k].x + v.y * cq[k].y + v.z * cq[k].z + v.w * cq[k].w;
-      }
-      val[s] = temp * dot;
-      const float ti = -1.0f + (float)i * step, tj = -1.0f + (float)j * step;
-      sp[s] = expf(-(ti * ti + tj * tj) / (2.0f * sg * sg));
-    }
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int t = lane + 64 * s2;
+    tv[s2] = t < d2;
+    const int ti = tv[s2] ? t / d : 0, tj = tv[s2] ? t % d : 0;
+    toff[s2] = ti * WT + tj;
+    const float fi = -1.0f + (float)ti * step, fj = -1.0f + (float)tj * step;
+    sp[s2] = tv[s2] ? expf(-(fi * fi + fj * fj) / (2.0f * sg * sg)) : 0.f;
   }
-  const float mx = wave_max(fmaxf(val[0], val[1]));
-  float e0 = expf(val[0] - mx), e1 = expf(val[1] - mx);          // exp(-inf) = 0 for the unused lanes
-  const float inv = 1.0f / wave_sum(e0 + e1);
-  e0 = e0 * inv * sp[0]; e1 = e1 * inv * sp[1];
-  const float nrm = fmaxf(wave_sum(e0 + e1), 1e-7f);
-  float* xr = X + pix * ldx;
-  if (lane < d2) xr[lane] = e0 / nrm;
-  if (lane + 64 < d2) xr[lane + 64] = e1 / nrm;
-  if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
-  if (X16) {                                               // bf16 copy, zero-padded to ldx16 columns: the A operand of the fixup GEMM
-    bf16_t* x16 = X16 + pix * ldx16;
-    for (int t = lane; t < ldx16; t += 64) {
-      float v = 0.f;
-      if (t < d2) v = (t < 64 ? e0 : e1) / nrm;
-      else if (t < d2 + 3) v = gs[pix * 3 + (t - d2)];
-      x16[t] = f2bf(v);
+  for (int pp = 0; pp < 16; ++pp) {
+    const int pxl = wave * 16 + pp, py = pxl >> 3, px = pxl & 7;
+    const int y = ty0 + py, x = tx0 + px;
+    if (y >= H || x >= W) continue;                        // wave-uniform
+    const int64_t pix = img + (int64_t)y * W + x;
+    const float* cqp = jk_sm + ((py + r) * WT + (px + r)) * JK_LD;
+    float4 cq[KEY_DIM / 4];
+#pragma unroll
+    for (int k = 0; k < KEY_DIM / 4; ++k) cq[k] = *reinterpret_cast<const float4*>(cqp + 4 * k);
+    float val[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      val[s2] = -INFINITY;
+      if (tv[s2]) {
+        const float* q = jk_sm + (py * WT + px + toff[s2]) * JK_LD;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < KEY_DIM / 4; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(q + 4 * k);
+          dot += v.x * cq[k].x + v.y * cq[k].y + v.z * cq[k].z + v.w * cq[k].w;
+        }
+        val[s2] = temp * dot;
+      }
+    }
+    const float mx = wave_max(fmaxf(val[0], val[1]));
+    float e0 = expf(val[0] - mx), e1 = expf(val[1] - mx);          // exp(-inf) = 0 for the unused lanes
+    const float inv = 1.0f / wave_sum(e0 + e1);
+    e0 = e0 * inv * sp[0]; e1 = e1 * inv * sp[1];
+    const float nrm = fmaxf(wave_sum(e0 + e1), 1e-7f);
+    float* xr = X + pix * ldx;
+    if (lane < d2) xr[lane] = e0 / nrm;
+    if (lane + 64 < d2) xr[lane + 64] = e1 / nrm;
+    if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
+    if (X16) {
+      bf16_t* x16 = X16 + pix * ldx16;
+      for (int t = lane; t < ldx16; t += 64) {
+        float v = 0.f;
+        if (t < d2) v = (t < 64 ? e0 : e1) / nrm;
+        else if (t < d2 + 3) v = gs[pix * 3 + (t - d2)];
+        x16[t] = f2bf(v);
+      }
     }
   }
 }
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(256) void jbu_bicubic_kernel(const float* __restric
 // ---- adaptive convolution, channels-last, reflect padding folded into the window staging ---------------------------------------
 // Workgroup = 8x8 output pixels x 32 channels.  LDS holds the (8+2r)^2 reflect-indexed window of those 32 channels (row stride
 // 36 floats: conflict-free 16-byte reads across a row of pixels) and the 64 pixels' d*d weights (tap-major).
-constexpr int AC_T = 8, AC_CC = 32, AC_LD = 36;
+constexpr int AC_CC = 32, AC_LD = 36;
 __global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const float* __restrict__ hr, const float* __restrict__ Kf, int ldk, int H, int W,
                                                                 int C, int r, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -557,9 +582,19 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
     SG_LAUNCH_CHECK();
     const bool fast = precision == SG_PREC_BF16 && C % 8 == 0;       // throughput mode: bf16 MFMA for the fixup linears and the convolution
     const int NP = jbu_np(r), KP1 = jbu_kp1(r), ldk = fast ? NP : d2;
-    hipLaunchKernelGGL(jbu_kernel_kernel, dim3((unsigned)cdiv(pixels, 4)), dim3(256), 0, s, p.proj, p.gs, B, oh, ow, r, S.range_temp, S.sigma, p.X,
-                       fast ? p.X16 : nullptr, KP1);
-    SG_LAUNCH_CHECK();
+    {
+      const int WT = AC_T + 2 * r;
+      const size_t lds = (size_t)WT * WT * JK_LD * sizeof(float);
+      static bool jk_attr = false;
+      if (!jk_attr) {
+        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jbu_kernel_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        jk_attr = true;
+      }
+      SG_REQUIRE(lds <= 64 * 1024, "sg_jbu_upsample: window %d too large", d);
+      hipLaunchKernelGGL(jbu_kernel_tiled_kernel, dim3((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B), dim3(256), lds, s, p.proj, p.gs, oh,
+                         ow, r, S.range_temp, S.sigma, p.X, fast ? p.X16 : nullptr, KP1);
+      SG_LAUNCH_CHECK();
+    }
     SG_REQUIRE(pixels < (1ll << 31), "sg_jbu_upsample: too many pixels");
     if (fast) {  // H1 = GELU(X . W0^T + b0) (bf16);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3), columns >= d2 are padding
       GemmBf16Args g{};
