@@ -7,10 +7,11 @@
 //   guidance pool (adaptive_avg_pool2d)                       jbu_pool_kernel
 //   range_proj: conv1x1(3->32) . GELU . conv1x1(32->32)       jbu_range_proj_kernel
 //   range kernel: softmax_p(temp * <proj[window p], proj[centre]>) over the reflect-padded d x d window,
-//     * spatial gaussian, / sum.clamp(1e-7)                   jbu_kernel_kernel   (one wave per pixel, taps on lanes)
-//   fixup: K += 0.1 * conv1x1(GELU(conv1x1([K, guidance])))   two f32-MFMA GEMMs over [pixels, d^2(+3)]
-//   hr = bicubic 2x (A=-0.75, align_corners=False)            jbu_bicubic2x_kernel
-//   adaptive conv with reflect padding                        jbu_adaptive_conv_kernel (LDS-staged window + weights)
+//     * spatial gaussian, / sum.clamp(1e-7)                   jbu_kernel_tiled_kernel (8x8 pixel block, window in LDS, taps on lanes)
+//   fixup: K += 0.1 * conv1x1(GELU(conv1x1([K, guidance])))   two GEMMs over [pixels, d^2(+3)]: f32 MFMA (parity) / bf16 MFMA, padded (throughput)
+//   hr = bicubic 2x (A=-0.75, align_corners=False)            jbu_bicubic_kernel (f32, or bf16 in throughput mode)
+//   adaptive conv with reflect padding                        jbu_adaptive_conv_kernel (parity: LDS-staged window + weights, VALU)
+//                                                             jbu_adaptive_conv_mfma_kernel (throughput: windowed GEMM on the matrix cores)
 // then  out = x + 0.1 * conv1x1_CxC(x)  (JBUOne/JBUStack.forward :301,325) as one GEMM with a residual epilogue.
 #include <string>
 #include <vector>
