@@ -218,7 +218,7 @@ def main():
                          "algorithmic_gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3), "events_dropped": g_drop,
                          "attention": {"kernel": "attn_kernel", "achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else 0.0,
                                        "launches": a_n, "avg_launch_us": round(a_ms * 1e3 / max(a_n, 1), 2)},
-                         "fp8_gemm": ({"kernel": "gemm_bf16_ring<256,128,...,FP8>", "achieved": round(f_fl / (f_ms * 1e-3) / 1e12, 2), "launches": f_n,
+                         "fp8_gemm": ({"kernel": "gemm_bf16_ring<256,256,2,4,2,FP8>", "achieved": round(f_fl / (f_ms * 1e-3) / 1e12, 2), "launches": f_n,
                                        "peak": 5000.0, "share_of_step_time": round(f_ms / (dt * 1e3), 4)} if f_n else None),
                          "share_of_step_time": {"gemm_bf16_persist": round(g_ms / (dt * 1e3), 4), "other_bf16_gemm": round(o_ms / (dt * 1e3), 4),
                                                 "attention": round(a_ms / (dt * 1e3), 4)}},

@@ -1033,7 +1033,8 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   GemmBf16Args h = a;                                       // the same bytes seen as a bf16 matrix of half the width
   h.K = a.K / 2; h.lda = a.lda / 2; h.ldw = a.ldw / 2; h.strideA = a.strideA / 2; h.strideW = a.strideW / 2;
   prof_begin(PROF_GEMM_FP8, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
-  const int rc = (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 128, 4, 2, 3, 0, 64, true>(h, vec, s)
+  // 256 x 256 x 128 B, two stages (1.47 / 1.32 / 1.64 PFLOP/s on the QKV / fc / proj shapes; the 256 x 128 three-stage tile 1.31 / 1.04 / 1.45)
+  const int rc = (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s)
                                              : launch_ring<128, 128, 2, 2, 3, 0, 64, true>(h, vec, s);
   prof_end(PROF_GEMM_FP8, s);
   if (rc != SG_OK) return rc;
