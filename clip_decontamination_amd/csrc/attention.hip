@@ -63,7 +63,7 @@ __device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u
 // Lean variants are capped at 256 registers (VGPR-form MFMA, 2+ waves per SIMD); the register-hungry ones (bias + multi-stream,
 // head_dim > 64) may take the whole file rather than spill.
 template <int DH, int TS, bool GENERIC, bool MULTI>
-__global__ __launch_bounds__(256, ((GENERIC && MULTI) || DH > 64) ? 1 : 2) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC || MULTI || DH > 80))) ? 1 : 2) void attn_kernel(AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = TS * KT * C::K_LD + KT * C::V_LD;                 // elements per LDS buffer: [TS K tiles][V tile]
