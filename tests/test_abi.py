@@ -97,3 +97,31 @@ def test_struct_layouts_match_header():
     assert vals[3] == _lib.TileBatch.n_tiles.offset
     assert vals[4] == _lib.ForwardOpts.gem_depth.offset
     assert vals[5] == _lib.TileBatch.scene_stride.offset
+
+
+def test_product_path_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package, the drop-in entry points or configs/ may import it; bench.py may
+    only do so inside cpu_baseline(), __graft_entry__ only inside smoke()."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node)
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append(node)
+        return tree, hits
+
+    product = glob.glob(os.path.join(root, "clip_decontamination_amd", "*.py")) + [os.path.join(root, f) for f in ("segmentor.py", "segearth_segmentor.py")]
+    product += glob.glob(os.path.join(root, "configs", "*.py"))
+    for path in product:
+        assert not oracle_imports(path)[1], f"{path} imports the oracle"
+    for path, allowed in ((os.path.join(root, "bench.py"), "cpu_baseline"), (os.path.join(root, "__graft_entry__.py"), "smoke")):
+        tree, hits = oracle_imports(path)
+        inside = [n for f in ast.walk(tree) if isinstance(f, ast.FunctionDef) and f.name == allowed for n in ast.walk(f)]
+        for h in hits:
+            assert any(h is n for n in inside), f"{path}: oracle import outside {allowed}()"
