@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--tile-cols", type=int, default=TILE_COLS, help="tiles per scene row")
     ap.add_argument("--tile-rows", type=int, default=TILE_ROWS_PER_RANK, help="tile rows per rank (weak scaling: the scene grows with the ranks)")
     ap.add_argument("--tiles-per-launch", type=int, default=0, help="0 = all of a rank's tiles in one launch of the tower")
+    ap.add_argument("--streams", type=int, default=1, help="experiment: split a rank's tiles over this many HIP streams (tails of one half overlap the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -142,8 +143,25 @@ def main():
     l, r, t, b = 3, 3, 3, 3                                           # compute_padsize(512, 512, 14)
     up = (TILE + t + b, TILE + l + r)
 
+    side = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else []
+
+    def tower():
+        if not side:
+            return pipe.tile_logits(slab, my_local, (TILE, TILE))
+        cur = torch.cuda.current_stream()
+        per = (len(my_local) + len(side) - 1) // len(side)
+        parts = []
+        for i, st in enumerate(side):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                parts.append(pipe.tile_logits(slab, my_local[i * per:(i + 1) * per], (TILE, TILE)))
+        for st, part in zip(side, parts):
+            cur.wait_stream(st)
+            part.record_stream(cur)
+        return torch.cat(parts, 0)
+
     def step():
-        tl = pipe.tile_logits(slab, my_local, (TILE, TILE))           # [tiles of this rank, Q, 37, 37]
+        tl = tower()                                                  # [tiles of this rank, Q, 37, 37]
         if world > 1:
             gathered = [torch.empty_like(tl) for _ in range(world)]
             dist.all_gather(gathered, tl)                             # RCCL over xGMI: 44 kB per tile

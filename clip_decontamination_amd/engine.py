@@ -134,12 +134,17 @@ class HipVisionTower:
         return o
 
     def _workspace(self, nbytes: int):
-        if self._ws is None or self._ws.numel() < nbytes + 256:
-            self._ws = None
-            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
-        p = self._ws.data_ptr()
+        """One arena per stream: forwards issued on different streams may overlap on the device and must not share scratch."""
+        if self._ws is None:
+            self._ws = {}
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes + 256:
+            self._ws[key] = None
+            ws = self._ws[key] = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        p = ws.data_ptr()
         off = (-p) % 256
-        return C.c_void_p(p + off), self._ws.numel() - off
+        return C.c_void_p(p + off), ws.numel() - off
 
     # -- the tower ------------------------------------------------------------------------------------
     def forward_tiles(self, scene: torch.Tensor, windows: torch.Tensor, tile_hw: Tuple[int, int], opts: ForwardOpts,

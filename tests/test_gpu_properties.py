@@ -69,3 +69,23 @@ def test_full_scene_slide_runs_and_is_deterministic(pipe):
     b = pipe.forward_slide(scene, 256, 512)
     assert a.shape == (1, len(QIDX), 1280, 1536) and torch.equal(a, b)
     assert torch.isfinite(a).all()
+
+
+def test_two_streams_do_not_share_scratch(pipe):
+    """Forwards issued on two HIP streams may overlap on the device (bench.py --streams 2): each stream has its own workspace arena,
+    and the halves must equal the same tiles computed one after the other."""
+    scene = torch.from_numpy(Wt.make_tiles_u8(1, 1536, seed=5, smooth=True)[0]).to(DEV)
+    wins = [(y, y + 512, x, x + 512) for y in (0, 512, 1024) for x in (0, 256, 512, 1024)]
+    ref_a = pipe.tile_logits(scene, wins[:6], (512, 512)).clone()
+    ref_b = pipe.tile_logits(scene, wins[6:], (512, 512)).clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    for rep in range(3):
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            a = pipe.tile_logits(scene, wins[:6], (512, 512))
+        with torch.cuda.stream(s2):
+            b = pipe.tile_logits(scene, wins[6:], (512, 512))
+        cur.wait_stream(s1); cur.wait_stream(s2)
+        a.record_stream(cur); b.record_stream(cur)
+        assert torch.equal(a, ref_a) and torch.equal(b, ref_b)
