@@ -391,3 +391,17 @@ def test_ctd_edge_cases(ops):
     # fewer points than min_samples
     out, labels = ops.ctd_debias(x[:, :5].contiguous().to(DEV), cls.to(DEV))
     assert (labels == -1).all()
+
+
+def test_known_answer_centre_of_a_3x3_grid(ops):
+    """Reference test_som.py:130-182 (the repo's only known-answer vector): centre of a 3 x 3 grid of 1..9 -> neighbour mean 5.0."""
+    feats = torch.arange(1, 10, dtype=torch.float32).reshape(1, 9, 1).repeat(1, 1, 4)
+    feats[0, 4] = 100.0
+    a_cls = torch.zeros(1, 10); a_cls[0, 5] = 1.0              # token 4 (+1 for CLS) has all the CLS attention
+    a_diag = torch.full((1, 10), 0.5)
+    out, idx = ops.outlier_suppress(feats.to(DEV), a_cls.to(DEV), a_diag.to(DEV), 3, 3, 1, 0.0)
+    assert idx.cpu().tolist() == [[4]]
+    assert torch.allclose(out[0, 4].cpu(), torch.full((4,), 5.0), atol=1e-5)
+    out2, idx2 = ops.weak_token_replace(feats.to(DEV), torch.tensor([[0.5, 0.9, 0.9, 0.9, 0.9, 0.1, 0.9, 0.9, 0.9, 0.9]]).to(DEV), 3, 3, 1)
+    assert idx2.cpu().tolist() == [[4]]
+    assert torch.allclose(out2[0, 4].cpu(), torch.full((4,), 5.0), atol=1e-5)

@@ -216,3 +216,15 @@ def test_cluster_then_debias(golden, tag):
     assert np.array_equal(labels.numpy(), g[f"{tag}.labels"])
     assert maxdiff(out, g[f"{tag}.out"]) < 1e-5
     assert labels.max() >= 1 and (labels < 0).any()          # several clusters and some noise: the case is not degenerate
+
+
+def test_known_answer_centre_of_a_3x3_grid():
+    """The one known-answer vector in the reference's tests (test_som.py:130-182, written for a module that no longer exists): the
+    centre of a 3 x 3 grid holding 1..9 is an outlier and is replaced by the mean of its 8 neighbours, 5.0.  With every channel
+    equal the cosine weights of mean_interpolation are uniform, so the shipped module must reproduce it."""
+    grid = torch.arange(1, 10, dtype=torch.float32).reshape(1, 1, 3, 3).repeat(1, 4, 1, 1)
+    grid[0, :, 1, 1] = 100.0                                   # the outlier value itself must not matter
+    out = OR.suppress_outliers(grid, torch.tensor([[4]]), contamination_temp=0.0)
+    assert torch.allclose(out[0, :, 1, 1], torch.full((4,), 5.0), atol=1e-6)
+    weak = OR.replace_weak_tokens(grid, torch.tensor([[4]]))
+    assert torch.allclose(weak[0, :, 1, 1], torch.full((4,), 5.0), atol=1e-6)
