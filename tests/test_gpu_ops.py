@@ -405,3 +405,20 @@ def test_known_answer_centre_of_a_3x3_grid(ops):
     out2, idx2 = ops.weak_token_replace(feats.to(DEV), torch.tensor([[0.5, 0.9, 0.9, 0.9, 0.9, 0.1, 0.9, 0.9, 0.9, 0.9]]).to(DEV), 3, 3, 1)
     assert idx2.cpu().tolist() == [[4]]
     assert torch.allclose(out2[0, 4].cpu(), torch.full((4,), 5.0), atol=1e-5)
+
+
+def test_new_entry_points_reject_bad_arguments(ops):
+    import ctypes as C
+    from clip_decontamination_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1, 16, 8, device=DEV)
+    cls = torch.zeros(1, 8, device=DEV)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    assert lib.sg_ctd_debias(P(x), P(cls), 1, 16, 6, C.c_double(1.1), 11, C.c_float(-1.5), 0, None, P(buf), buf.numel(), None) != 0   # C % 4
+    assert b"multiple of 4" in lib.sg_last_error()
+    assert lib.sg_ctd_debias(P(x), P(cls), 1, 16, 8, C.c_double(1.1), 11, C.c_float(-1.5), 0, None, P(buf), 16, None) != 0            # scratch too small
+    assert b"scratch" in lib.sg_last_error()
+    assert lib.sg_render_maps(None, None, None, 3, 4, 4, P(buf), None, None) != 0                                                   # mask without labels
+    assert lib.sg_gemm_fp8_raw(P(buf), P(cls), P(buf), P(cls), None, None, P(x), 4, 8, 64, 0, 0, None) != 0                          # K % 128
+    assert b"128" in lib.sg_last_error()

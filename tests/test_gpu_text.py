@@ -103,3 +103,24 @@ def test_query_features_ensemble_and_segmentor_route(tmp_path):
     assert seg.query_features.shape == (4, tc.embed_dim) and seg.query_idx.tolist() == [0, 1, 2, 2]
     assert (seg.query_features[:2].cpu() - ref[:2]).abs().max().item() < 1e-4
     assert seg.net.encode_text(tokenizer(["a photo of a road."])).shape == (1, tc.embed_dim)
+
+
+def test_text_tower_error_paths():
+    """Loud failures, no silent fallback: incomplete weights, wrong token shape, unknown tensor names."""
+    import ctypes as C
+    from clip_decontamination_amd import _lib
+    from clip_decontamination_amd.engine import HipTextTower
+    tc = Wt.TEXT_CONFIGS["tiny-text"]
+    w = Wt.make_text_weights(tc, seed=0)
+    partial = {k: v for k, v in w.items() if k != "ln_final.bias"}
+    tt = HipTextTower(tc, partial, precision="f32", device="cuda:0")
+    with pytest.raises(RuntimeError, match="incomplete"):
+        tt.encode_text(torch.from_numpy(Wt.make_token_ids(tc, 2)))
+    full = HipTextTower(tc, w, precision="f32", device="cuda:0")
+    with pytest.raises(ValueError):
+        full.encode_text(torch.zeros(2, tc.context_length + 1, dtype=torch.int64))
+    lib = _lib.load()
+    t = torch.zeros(4, device="cuda:0")
+    rc = lib.sg_text_set_tensor(full._ctx, b"visual.proj", C.c_void_p(t.data_ptr()), 4, None)
+    assert rc != 0 and b"unknown tensor" in lib.sg_last_error()
+    assert full.encode_text(torch.zeros(0, tc.context_length, dtype=torch.int64)).shape == (0, tc.embed_dim)   # empty batch
