@@ -2,8 +2,9 @@
 
 Mirrors reference segmentor.py: ``forward_feature`` (:286-392), ``forward_slide`` (:394-451),
 ``postprocess_result`` (:475-499) -- but tiles are cropped / padded / embedded on the device in batches,
-stitched write-once, and (optionally) partitioned over the ranks of a torch.distributed group with ONE
-all-gather of the per-tile patch-grid logit maps.
+stitched write-once, and (opt-in: ``tile_group``) partitioned over the ranks of a torch.distributed group with ONE
+all-gather of the per-tile patch-grid logit maps; per-pixel logit maps (JBU upsampler) travel point to
+point instead, only the tiles that straddle a canvas-band edge.  Every rank stitches and labels its own canvas band.
 """
 from __future__ import annotations
 
@@ -38,21 +39,120 @@ def partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _is_nccl(group) -> bool:
+    return torch.distributed.get_backend(group) == "nccl"
+
+
+def resolve_tile_group(group):
+    """Tile sharding is OPT-IN: ``None`` = this process handles the whole scene (the reference's own multi-GPU launch shards IMAGES
+    over ranks, dist_test.sh -> mmengine DefaultSampler, so an initialised default process group must NOT trigger tile sharding);
+    ``"world"`` = the default group; otherwise a torch.distributed ProcessGroup."""
+    if group is None:
+        return None
+    if isinstance(group, str):
+        if group != "world":
+            raise ValueError(f"tile_group must be None, 'world' or a ProcessGroup, got {group!r}")
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise RuntimeError("tile_group='world' needs an initialised torch.distributed process group")
+        return torch.distributed.group.WORLD
+    return group
+
+
+def check_same_scene(desc: Sequence[int], device, group) -> None:
+    """Every rank of a tile group must hold the SAME scene geometry (H, W, tile count, crop, stride ...): ranks that hold
+    different images would silently mix tiles of different scenes in the gather.  One tiny all-gather per scene."""
+    world = torch.distributed.get_world_size(group)
+    dev = device if _is_nccl(group) else torch.device("cpu")
+    mine = torch.tensor(list(desc), dtype=torch.int64, device=dev)
+    allv = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
+    torch.distributed.all_gather_into_tensor(allv, mine, group=group)
+    allv = allv.reshape(world, -1).cpu()
+    if not bool((allv == allv[0]).all()):
+        raise RuntimeError("tile sharding: the ranks of the tile group hold different scenes "
+                           f"(per-rank [H, W, tiles, crop_h, crop_w, stride_h, stride_w, Q]: {allv.tolist()}); "
+                           "every rank must be given the same image")
+
+
 def gather_blocks(local: torch.Tensor, n_items: int, world: int, rank: int, group=None) -> torch.Tensor:
     """All-gather of per-rank blocks of the raster tile list (``partition``): ``local`` holds this rank's items (possibly followed
     by padding); returns the full [n_items, ...] list on every rank.  Blocks are padded to ceil(n_items / world) so the
-    collective is fixed-size (RCCL over xGMI on GPUs)."""
+    collective is fixed-size: ONE all_gather_into_tensor (RCCL over xGMI on GPUs) into a preallocated buffer, which IS the result
+    when the tile count divides evenly."""
     lo, hi = partition(n_items, world, rank)
     t_pad = (n_items + world - 1) // world
-    block = local.new_zeros((t_pad,) + tuple(local.shape[1:]))
+    tail = tuple(local.shape[1:])
+    buf = local.new_empty((world * t_pad,) + tail)
+    block = local.new_zeros((t_pad,) + tail)
     block[:hi - lo] = local[:hi - lo]
-    gathered = [torch.empty_like(block) for _ in range(world)]
-    torch.distributed.all_gather(gathered, block, group=group)
+    torch.distributed.all_gather_into_tensor(buf, block, group=group)
+    if n_items == world * t_pad:
+        return buf
     parts = []
     for r in range(world):
         a, b = partition(n_items, world, r)
-        parts.append(gathered[r][:b - a])
+        parts.append(buf[r * t_pad:r * t_pad + (b - a)])
     return torch.cat(parts, 0)
+
+
+def band_plan(wins: Sequence[Tuple[int, int, int, int]], H: int, world: int):
+    """Canvas bands for a band-local stitch: rank r owns canvas rows [yb[r], yb[r+1]) where yb[r] is the first row of its first
+    tile (raster order, ``partition``); need[r] = (a, b) is the contiguous range of tile ids that overlap the band.  Because y1 is
+    non-decreasing in raster order, need[r] = [a_r, hi_r) with a_r <= lo_r: a rank only ever needs tiles of LOWER ranks (the
+    halo), never of higher ones."""
+    T = len(wins)
+    yb = []
+    for r in range(world):
+        lo, hi = partition(T, world, r)
+        yb.append(0 if r == 0 else (wins[lo][0] if hi > lo else H))
+    yb.append(H)
+    for r in range(world - 1, 0, -1):                      # empty blocks sit at the end; keep yb monotone
+        yb[r] = min(yb[r], yb[r + 1])
+    need = []
+    for r in range(world):
+        lo, hi = partition(T, world, r)
+        if yb[r + 1] <= yb[r]:
+            need.append((lo, lo))
+            continue
+        a = lo
+        while a > 0 and wins[a - 1][1] > yb[r]:
+            a -= 1
+        need.append((a, hi))
+    return yb, need
+
+
+def exchange_halo_tiles(local: torch.Tensor, wins, world: int, rank: int, group=None, plan=None) -> Tuple[torch.Tensor, int]:
+    """Band-local stitch, step 1: every rank receives the tile logits of LOWER ranks that overlap its canvas band, point to
+    point (xGMI is point-to-point: only the tiles that straddle a band edge travel, instead of all-gathering [T,Q,S,S] per-pixel
+    logits to everyone).  Returns (tile logits of tiles [a, hi) in raster order, a)."""
+    T = len(wins)
+    yb, need = plan if plan is not None else band_plan(wins, wins[-1][1], world)
+    lo, hi = partition(T, world, rank)
+    owner = [r for r in range(world) for _ in range(partition(T, world, r)[1] - partition(T, world, r)[0])]
+    dist = torch.distributed
+    peer = (lambda r: r) if group is None or group is dist.group.WORLD else (lambda r: dist.get_global_rank(group, r))
+    staged = (not _is_nccl(group)) and local.is_cuda      # gloo moves host memory only
+    a, b = need[rank]
+    halo = local.new_empty((lo - a,) + tuple(local.shape[1:]), device="cpu" if staged else local.device)
+    ops_, keep = [], []
+    src = local.cpu() if staged else local
+    for r in range(rank + 1, world):                      # my tiles that a higher rank's band needs
+        ra, _ = need[r]
+        s0, s1 = max(ra, lo), hi
+        if partition(T, world, r)[1] > partition(T, world, r)[0] and s1 > s0 and ra < hi:
+            t = src[s0 - lo:s1 - lo].contiguous()
+            keep.append(t)
+            ops_.append(dist.P2POp(dist.isend, t, peer(r), group))
+    t0 = a
+    while t0 < lo:                                        # tiles [a, lo) come from their owners, one message per owner
+        o = owner[t0]
+        t1 = min(partition(T, world, o)[1], lo)
+        ops_.append(dist.P2POp(dist.irecv, halo[t0 - a:t1 - a], peer(o), group))
+        t0 = t1
+    if ops_:
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+    halo = halo.to(local.device) if staged else halo
+    return (torch.cat([halo, local[:hi - lo]], 0) if lo > a else local[:hi - lo]), a
 
 
 def sharded_cross_tile_fusion(tokens: torch.Tensor, steps, n_tiles: int, world: int, rank: int, group=None) -> torch.Tensor:
@@ -78,7 +178,8 @@ class SegPipeline:
     def __init__(self, net: HipCLIP, text: torch.Tensor, query_idx: torch.Tensor, model_type: str = "SegEarth",
                  ignore_residual: bool = True, cls_token_lambda: float = 0.0, global_debias_factor: float = 0.0,
                  logit_scale: float = 50.0, prob_thd: float = 0.0, bg_idx: int = 0, apply_similarity_enhancement: bool = False,
-                 upsampler=None, tiles_per_launch: int = 32, cross_tile_fusion: Optional[dict] = None, apply_ctd: bool = False):
+                 upsampler=None, tiles_per_launch: int = 32, cross_tile_fusion: Optional[dict] = None, apply_ctd: bool = False,
+                 tile_group=None):
         self.net = net
         self.visual = net.visual
         self.device = self.visual.device
@@ -97,6 +198,13 @@ class SegPipeline:
         # opt-in: the reference ships CrossTileFusion but never calls it; kwargs of its constructor
         self.cross_tile_fusion = cross_tile_fusion
         self.apply_ctd = bool(apply_ctd)                 # Cluster-Then-Debias (segmentor.py:339-365), SegmentorEx only
+        # Tile sharding over ranks is opt-in (None = off, "world" = the default process group, or a ProcessGroup whose ranks
+        # all hold the SAME scene).  It is never inferred from torch.distributed being initialised: under the reference's own
+        # multi-GPU launch every rank holds a different image.
+        self.tile_group = tile_group
+
+    def _stitch(self, tile_logits, windows, up_hw, pad_tl, canvas_hw):
+        return ops.stitch(tile_logits, windows, up_hw, pad_tl, canvas_hw)
 
     def _pre_head(self, tok, cls):
         """Global debias (+ CTD) when they cannot stay fused in the logits kernel: returns (tokens, remaining debias factor)."""
@@ -153,8 +261,7 @@ class SegPipeline:
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
     # -- reference forward_slide -----------------------------------------------------------------------------
-    def forward_slide(self, scene: torch.Tensor, stride, crop, ori_shape=None, group=None) -> torch.Tensor:
-        """scene: f32 [3,H,W] normalised planes or u8 [H,W,3].  Returns logits [1,Q,H_ori,W_ori]."""
+    def _geometry(self, scene, stride, crop):
         if scene.dtype == torch.uint8:
             H, W = int(scene.shape[0]), int(scene.shape[1])
         else:
@@ -166,24 +273,84 @@ class SegPipeline:
         P = self.visual.cfg.patch
         l, r, t, b = compute_padsize(tile_hw[0], tile_hw[1], P)
         up_hw = (tile_hw[0] + t + b, tile_hw[1] + l + r)
-        world, rank = 1, 0
-        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
         hg = max(H - crop[0] + stride[0] - 1, 0) // stride[0] + 1
         wg = max(W - crop[1] + stride[1] - 1, 0) // stride[1] + 1
-        if world == 1:
-            tl = self.tile_logits(scene, wins, tile_hw, grid_of_tiles=(hg, wg))
+        return H, W, stride, crop, wins, tile_hw, (t, l), up_hw, (hg, wg)
+
+    def forward_slide(self, scene: torch.Tensor, stride, crop, ori_shape=None, group=None) -> torch.Tensor:
+        """scene: f32 [3,H,W] normalised planes or u8 [H,W,3].  Returns logits [1,Q,H_ori,W_ori] (on every rank of the tile
+        group when sharding is on: ``group`` overrides ``self.tile_group``; None = this process does the whole scene)."""
+        H, W, stride, crop, wins, tile_hw, pad_tl, up_hw, grid = self._geometry(scene, stride, crop)
+        group = resolve_tile_group(group if group is not None else self.tile_group)
+        if group is None:
+            tl = self.tile_logits(scene, wins, tile_hw, grid_of_tiles=grid)
+            win_dev = torch.tensor(wins, dtype=torch.int32, device=self.device)
+            canvas = self._stitch(tl, win_dev, up_hw, pad_tl, (H, W))
         else:
-            tl = self.gather_tile_logits(scene, wins, tile_hw, world, rank, group, grid_of_tiles=(hg, wg))
-        win_dev = torch.tensor(wins, dtype=torch.int32, device=self.device)
-        if self.upsampler is not None:
-            up_hw_src = up_hw           # per-pixel logits: the bilinear resize inside stitch is the identity
-            canvas = ops.stitch(tl, win_dev, up_hw_src, (t, l), (H, W))
-        else:
-            canvas = ops.stitch(tl, win_dev, up_hw, (t, l), (H, W))
+            band, y0, yb = self.sharded_canvas_band(scene, stride, crop, group)
+            canvas = self.gather_bands(band, yb, H, group)
         if ori_shape is not None and tuple(ori_shape) != (H, W):
             canvas = ops.resize_bilinear(canvas, tuple(ori_shape))
         return canvas.unsqueeze(0)
+
+    def sharded_canvas_band(self, scene, stride, crop, group):
+        """Tiles partitioned over the ranks of ``group`` -> this rank's band of the stitched canvas: (band [Q, rows, W], first row,
+        band boundaries of all ranks).  Patch-grid logits (44 kB per tile) are rebuilt everywhere with ONE all-gather (RCCL over xGMI);
+        per-pixel logits (upsampler: 16-32 MB per tile) travel point to point, only the tiles that straddle a band edge.  Either way each
+        rank stitches ONLY its own band, so the tail scales with the ranks too; the band equals the same rows of the single-process
+        canvas bit for bit (the write-once stitch averages the covering tiles in raster order, and all of them are present)."""
+        H, W, stride, crop, wins, tile_hw, pad_tl, up_hw, grid = self._geometry(scene, stride, crop)
+        world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+        check_same_scene([H, W, len(wins), crop[0], crop[1], stride[0], stride[1], self.num_queries], self.device, group)
+        T = len(wins)
+        lo, hi = partition(T, world, rank)
+        plan = band_plan(wins, H, world)
+        yb, need = plan
+        if self.upsampler is None or self.cross_tile_fusion is not None:
+            tl = self.gather_tile_logits(scene, wins, tile_hw, world, rank, group, grid_of_tiles=grid)
+            a, b = need[rank]
+            tiles, first = tl[a:b], a
+        else:
+            mine = list(wins[lo:hi])
+            local = self.tile_logits(scene, mine if mine else [wins[0]], tile_hw)[:hi - lo]
+            tiles, first = exchange_halo_tiles(local, wins, world, rank, group, plan)
+        y0, y1 = yb[rank], yb[rank + 1]
+        if y1 <= y0:
+            return tiles.new_zeros((self.num_queries, 0, W)), y0, yb
+        w_band = torch.tensor(wins[first:first + tiles.shape[0]], dtype=torch.int32, device=self.device)
+        w_band[:, 0:2] -= y0
+        return self._stitch(tiles, w_band, up_hw, pad_tl, (y1 - y0, W)), y0, yb
+
+    def gather_bands(self, band: torch.Tensor, yb, H: int, group) -> torch.Tensor:
+        """[C, rows_r, W] bands of every rank -> the full [C, H, W] on every rank (one all_gather_into_tensor of bands padded to
+        the tallest one).  Used for the drop-in's full-canvas return value and for the label map."""
+        world = torch.distributed.get_world_size(group)
+        hmax = max(yb[r + 1] - yb[r] for r in range(world))
+        C_, W = band.shape[0], band.shape[-1]
+        block = band.new_zeros((C_, hmax, W))
+        block[:, :band.shape[1]] = band
+        buf = band.new_empty((world, C_, hmax, W))
+        torch.distributed.all_gather_into_tensor(buf.view(world * C_, hmax, W), block, group=group)   # output = concat along dim 0
+        if world == 1:
+            return buf[0, :, :H]
+        return torch.cat([buf[r, :, :yb[r + 1] - yb[r]] for r in range(world)], 1)
+
+    def segment_scene(self, scene: torch.Tensor, stride, crop, group=None, gather_labels: bool = True):
+        """The whole path to labels for one scene.  Sharded: every rank computes its tiles, stitches + labels ITS band; only the
+        int64 label band (8 B per pixel instead of 4Q) is gathered.  -> labels [1,H,W] (or (band labels, first row) when
+        ``gather_labels`` is False)."""
+        group = resolve_tile_group(group if group is not None else self.tile_group)
+        if group is None:
+            _, labels = self.postprocess(self.forward_slide(scene, stride, crop)[0], want_probs=False)
+            return labels
+        band, y0, yb = self.sharded_canvas_band(scene, stride, crop, group)
+        if band.shape[1] > 0:
+            _, lab = self.postprocess(band, want_probs=False)
+        else:
+            lab = torch.empty((1, 0, band.shape[-1]), dtype=torch.int64, device=band.device)
+        if not gather_labels:
+            return lab, y0
+        return self.gather_bands(lab, yb, yb[-1], group)
 
     def gather_tile_logits(self, scene, wins, tile_hw, world, rank, group=None, grid_of_tiles=None) -> torch.Tensor:
         """Rank r computes a contiguous block of the raster tile list; one all-gather (RCCL over xGMI on GPUs)

@@ -125,7 +125,8 @@ class _HipSegmentorBase(_Base):
     def _setup(self, clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                slide_crop, cls_token_lambda, bg_idx, apply_sim_feat_up, sim_feat_up_cfg, global_debias_factor=0.0,
                checkpoint=None, text_features=None, text_encoder: Optional[Callable] = None, precision="bf16",
-               synthetic_ok=False, tiles_per_launch=32, jbu_checkpoint_ok=True, tokenizer: Optional[Callable] = None):
+               synthetic_ok=False, tiles_per_launch=32, jbu_checkpoint_ok=True, tokenizer: Optional[Callable] = None, tile_group=None):
+        self.tile_group = tile_group                         # opt-in tile sharding (pipeline.resolve_tile_group); None = off
         if clip_type == "BLIP":
             raise NotImplementedError("clip_type='BLIP' is a different backbone (vendored BLIP) and is out of scope for the HIP path")
         self.clip_type, self.vit_type, self.model_type = clip_type, vit_type, model_type
@@ -218,7 +219,8 @@ class _HipSegmentorBase(_Base):
                            global_debias_factor=self.global_debias_factor, logit_scale=self.logit_scale, prob_thd=self.prob_thd,
                            bg_idx=self.bg_idx, apply_similarity_enhancement=getattr(self, "apply_similarity_enhancement", False),
                            upsampler=self.upsampler, tiles_per_launch=self._tiles_per_launch,
-                           cross_tile_fusion=getattr(self, "cross_tile_fusion_cfg", None), apply_ctd=getattr(self, "apply_ctd", False))
+                           cross_tile_fusion=getattr(self, "cross_tile_fusion_cfg", None), apply_ctd=getattr(self, "apply_ctd", False),
+                           tile_group=getattr(self, "tile_group", None))
 
     def forward_feature(self, img, logit_size=None, tile_h_idx=None, tile_w_idx=None):
         """Reference segmentor.py:286-392.  img [B,3,H,W] -> logits [B,Q,h,w]."""
@@ -330,7 +332,7 @@ class SegmentorEx(_HipSegmentorBase):
                  similarity_enhancement_cfg=None, result_dir=None, heatmap_dir=None,
                  # -- drop-in extras (see module docstring) --
                  checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
-                 tokenizer=None, cross_tile_fusion_cfg=None):
+                 tokenizer=None, cross_tile_fusion_cfg=None, tile_group=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
         if model_type == "GEM":
@@ -340,7 +342,8 @@ class SegmentorEx(_HipSegmentorBase):
             raise NotImplementedError("apply_layer_fusion is internally inconsistent in the reference (SURVEY.md R9) and is not built")
         visual = self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                              slide_crop, cls_token_lambda, bg_idx, _to_bool(apply_sim_feat_up), sim_feat_up_cfg, global_debias_factor,
-                             checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer)
+                             checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer,
+                             tile_group=tile_group)
         # opt-in extra: kwargs of the reference's CrossTileFusion (cross_tile_fusion.py:24-60), which the reference never calls (R2)
         self.cross_tile_fusion_cfg = cross_tile_fusion_cfg
         self.apply_ctd = _to_bool(apply_ctd)                                # segmentor.py:184-194, 339-365: DBSCAN + cluster debias, on the device here
@@ -371,14 +374,15 @@ class Segmentor(_HipSegmentorBase):
                  logit_scale=50, slide_stride=112, slide_crop=224, cls_token_lambda=0, bg_idx=0, apply_sim_feat_up=True,
                  sim_feat_up_cfg=dict(model_name="jbu_one", model_path="your/model/path"),
                  checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
-                 tokenizer=None, cross_tile_fusion_cfg=None):
+                 tokenizer=None, cross_tile_fusion_cfg=None, tile_group=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
         if model_type == "GEM" and cls_token_lambda != 0:
             raise ValueError("GEM returns no CLS token (gem_utils.py:198-199): cls_token_lambda must be 0 (SURVEY.md R5)")
         self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                     slide_crop, cls_token_lambda, bg_idx, apply_sim_feat_up, sim_feat_up_cfg, 0.0,
-                    checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer)
+                    checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer,
+                    tile_group=tile_group)
         # opt-in extra: kwargs of the reference's CrossTileFusion (cross_tile_fusion.py:24-60), which the reference never calls (R2)
         self.cross_tile_fusion_cfg = cross_tile_fusion_cfg
         self.output_cls_token = cls_token_lambda != 0

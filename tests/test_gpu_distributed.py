@@ -35,7 +35,7 @@ def _worker(rank, world, port, ctf, q):
     try:
         torch.cuda.set_device(0)
         pipe = _pipe(ctf)
-        out = pipe.forward_slide(_scene().cuda(), 32, 32)          # 3 x 4 = 12 tiles of 32, partitioned over the ranks
+        out = pipe.forward_slide(_scene().cuda(), 32, 32, group="world")   # 3 x 4 = 12 tiles of 32, partitioned over the ranks (opt-in)
         torch.cuda.synchronize()
         q.put((rank, out.cpu().numpy()))                           # by value: tensors travel as shared-memory fds that die with the child
     finally:
