@@ -3,6 +3,8 @@
 // allocations happen in sg_create (one arena sized from the architecture descriptor).
 #include <string>
 #include <vector>
+#include <mutex>
+#include <utility>
 #include <math.h>
 #include "rowops.h"
 
@@ -26,7 +28,33 @@ struct ProfState {
   double work[PROF_NCAT] = {};
   int64_t dropped[PROF_NCAT] = {};
 };
-static ProfState g_prof;
+// measurement state belongs to the CALLING THREAD (bench.py enables, launches and reads on one thread): two host threads driving
+// two contexts never share it
+static thread_local ProfState g_prof;
+
+static std::mutex g_dev_mu;                                        // guards the two per-device caches below
+static std::vector<std::pair<int, const void*>> g_lds_done;        // (device, kernel) pairs already opted in
+static std::vector<std::pair<int, int>> g_cu_count;               // (device, compute units)
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  int dev = 0;
+  SG_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  for (const auto& e : g_lds_done) if (e.first == dev && e.second == kernel) return SG_OK;
+  SG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  g_lds_done.emplace_back(dev, kernel);
+  return SG_OK;
+}
+int device_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  for (const auto& e : g_cu_count) if (e.first == dev) return e.second;
+  int n = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+  g_cu_count.emplace_back(dev, n);
+  return n;
+}
 bool prof_on() { return g_prof.on; }
 void prof_begin(int cat, double work, hipStream_t s) {
   if (!g_prof.on) return;
@@ -398,7 +426,7 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
     const int dh = d.width / d.heads;
     SG_REQUIRE(dh == 32 || dh == 64 || dh == 80 || dh == 128, "sg_create: bf16 mode supports head_dim 32/64/80/128, got %d", dh);
   }
-  SG_HIP(hipSetDevice(device));
+  DeviceGuard dg(device);
   sg_context* c = new sg_context();
   c->d = d; c->device = device; c->bf16 = d.precision != SG_PREC_F32; c->fp8 = d.precision == SG_PREC_FP8;
   c->esz = c->bf16 ? 2 : 4;
@@ -447,6 +475,7 @@ extern "C" void sg_destroy(sg_context* c) {
 
 extern "C" int sg_vit_set_tensor(sg_context* c, const char* name, const float* src, int64_t numel, sg_stream st) {
   SG_REQUIRE(c && name && src, "sg_vit_set_tensor: null argument");
+  DeviceGuard dg(c->device);
   hipStream_t s = as_stream(st);
   const sg_vit_desc& d = c->d;
   const int D = d.width, M = d.mlp_width, E = d.embed_dim;
@@ -598,6 +627,7 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
                               void* workspace, size_t workspace_bytes, sg_stream st) {
   SG_REQUIRE(c && tiles && o && out_tokens && workspace, "sg_vit_forward: null argument");
   if (!c->finalized) return fail(SG_ERR_STATE, "sg_vit_forward: weights not finalized (call sg_vit_finalize)");
+  DeviceGuard dg(c->device);                                          // the context's device, whatever the caller's current device is
   hipStream_t s = as_stream(st);
   const sg_vit_desc& d = c->d;
   const int B = tiles->n_tiles, gh = tiles->grid_h, gw = tiles->grid_w, n = gh * gw, N = n + 1;
@@ -734,13 +764,15 @@ struct sg_text {
 };
 
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ tok_emb,
-                                                         const float* __restrict__ pos, int S, int ctx, int W, int vocab, float* __restrict__ x) {
+                                                         const float* __restrict__ pos, int S, int ctx, int W, int vocab, float* __restrict__ x,
+                                                         int* __restrict__ bad_id) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)S * ctx * W) return;
   const int c = (int)(i % W);
   const int64_t row = i / W;
   const int t = (int)(row % ctx);
-  int id = tokens[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  int id = tokens[row];
+  if (id < 0 || id >= vocab) { if (c == 0) atomicMax(bad_id, 1); id = id < 0 ? 0 : vocab - 1; }   // reported by sg_text_encode; clamped only so the gather stays in bounds
   x[i] = tok_emb[(int64_t)id * W + c] + pos[(int64_t)t * W + c];
 }
 // pooled[s,:] = x[s, argmax_t tokens[s,t], :]   (text_global_pool 'argmax': the EOT token has the highest id; first maximum wins)
@@ -768,7 +800,7 @@ extern "C" int sg_text_create(sg_text** out, int device, int width, int layers, 
     const int dh = width / heads;
     SG_REQUIRE(width % 64 == 0 && (dh == 32 || dh == 64 || dh == 80 || dh == 128), "sg_text_create: bf16 mode needs width %% 64 == 0 and head_dim 32/64/80/128");
   }
-  SG_HIP(hipSetDevice(device));
+  DeviceGuard dg(device);
   sg_text* t = new sg_text();
   sg_context& c = t->core;
   c.d = sg_vit_desc{width, layers, heads, 1, embed_dim, 1, 4 * width, quick_gelu, precision};
@@ -804,6 +836,7 @@ extern "C" void sg_text_destroy(sg_text* t) {
 
 extern "C" int sg_text_set_tensor(sg_text* t, const char* name, const float* src, int64_t numel, sg_stream st) {
   SG_REQUIRE(t && name && src, "sg_text_set_tensor: null argument");
+  DeviceGuard dg(t->core.device);
   hipStream_t s = as_stream(st);
   sg_context& c = t->core;
   const int D = c.d.width, M = c.d.mlp_width, E = t->embed_dim;
@@ -866,6 +899,7 @@ static size_t text_plan(const sg_text* t, int S, void* ws, bool dry, Plan& p, fl
   p.scores = p.probs = nullptr;
   if (!c.bf16) { p.scores = b.get<float>((size_t)S * c.d.heads * N * N); p.probs = b.get<float>((size_t)S * c.d.heads * N * N); }
   pooled = b.get<float>((size_t)S * D);
+  p.idx_out = b.get<int32_t>(1);                            // out-of-vocabulary flag of text_embed_kernel
   return align_up(b.off, 256);
 }
 
@@ -879,6 +913,7 @@ extern "C" size_t sg_text_workspace_bytes(const sg_text* t, int n_seq) {
 extern "C" int sg_text_encode(sg_text* t, const int32_t* tokens, int n_seq, float* out, void* workspace, size_t workspace_bytes, sg_stream st) {
   SG_REQUIRE(t && tokens && out && workspace && n_seq > 0, "sg_text_encode: bad arguments");
   for (size_t i = 0; i < t->have_text.size(); ++i) if (!t->have_text[i]) return fail(SG_ERR_STATE, "sg_text_encode: text weights incomplete");
+  DeviceGuard dg(t->core.device);
   hipStream_t s = as_stream(st);
   sg_context& c = t->core;
   const int N = t->context_length, D = c.d.width, E = t->embed_dim, S = n_seq;
@@ -886,13 +921,21 @@ extern "C" int sg_text_encode(sg_text* t, const int32_t* tokens, int n_seq, floa
   Plan p{}; float *pooled, *x;
   const size_t need = text_plan(t, S, workspace, false, p, pooled, x);
   if (need > workspace_bytes) return fail(SG_ERR_STATE, "sg_text_encode: workspace %zu < required %zu", workspace_bytes, need);
-  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, tokens, t->tok_emb, t->pos_emb, S, N, D, t->vocab_size, x);
+  SG_HIP(hipMemsetAsync(p.idx_out, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, tokens, t->tok_emb, t->pos_emb, S, N, D, t->vocab_size, x, p.idx_out);
   SG_LAUNCH_CHECK();
   for (int i = 0; i < c.d.layers; ++i) SG_TRY(std_block(&c, c.layers[i], x, p, S, N, false, s, false, /*causal=*/true));
   hipLaunchKernelGGL(text_pool_kernel, dim3(S), dim3(256), 0, s, tokens, x, N, D, pooled);
   SG_LAUNCH_CHECK();
   SG_TRY(layernorm(pooled, D, t->lnf_g, t->lnf_b, p.xn, D, c.bf16, S, D, 1e-5f, s));
-  return linear(c.bf16, p.xn, D, t->w_projT, nullptr, nullptr, out, E, true, S, E, D, ACT_NONE, s);
+  SG_TRY(linear(c.bf16, p.xn, D, t->w_projT, nullptr, nullptr, out, E, true, S, E, D, ACT_NONE, s));
+  // init-time call: the one entry point that synchronises, so that an id outside the vocabulary is an error as in the reference
+  // (nn.Embedding raises, open_clip/model.py:292) instead of a silently clamped row
+  int32_t bad = 0;
+  SG_HIP(hipMemcpyAsync(&bad, p.idx_out, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
+  if (bad) return fail(SG_ERR_INVALID, "sg_text_encode: token id outside [0, %d)", t->vocab_size);
+  return SG_OK;
 }
 
 // ---- stand-alone ops ------------------------------------------------------------------------------------------------------

@@ -47,6 +47,19 @@ int fail(int code, const char* fmt, ...);
     if (_rc != SG_OK) return _rc;                                                            \
   } while (0)
 
+// ---- per-device launch bookkeeping: no per-process "done once" flags (a second device / a second host thread must work) ----
+// ensure_dynamic_lds: opt a kernel in to `bytes` of dynamic LDS on the CURRENT device, once per (device, kernel), thread-safe.
+// device_cu_count: compute units of the current device (cached per device).  DeviceGuard: make a context's device current for
+// the duration of an entry point (a context created on cuda:1 must launch on cuda:1 whatever the caller's current device is).
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
+int device_cu_count();
+struct DeviceGuard {
+  int prev = -1, dev;
+  explicit DeviceGuard(int d) : dev(d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+  ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete; DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 static inline hipStream_t as_stream(sg_stream s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
@@ -107,7 +120,7 @@ struct GemmBf16Args {
   int fp8; const float* row_scale; const float* col_scale;
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
-void set_gemm_config(int c);   // tuning hook: -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
+void set_gemm_config(int c);   // tuning hook (per calling thread): -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
 
 // f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];
 // B(k,n) at B[k*sbk + n*sbn]; two-level batch: z -> (z / inner, z % inner).

@@ -280,11 +280,7 @@ extern "C" int sg_ctd_debias(float* tokens, const float* cls, int B, int n, int 
                      min_samples, W, q.adj, q.core);
   SG_LAUNCH_CHECK();
   const size_t lds = (size_t)(2 * n + ((2 * n) & 1)) * 4 + (size_t)W * 8 + 1024 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ctd_components_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
-  }
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ctd_components_kernel), 96 * 1024));
   hipLaunchKernelGGL(ctd_components_kernel, dim3(B), dim3(1024), lds, s, q.adj, q.core, n, W, q.labels, q.ncl);
   SG_LAUNCH_CHECK();
   hipLaunchKernelGGL(ctd_proto_sim_kernel, dim3(n, B), dim3(256), 0, s, tokens, cls, q.labels, q.ncl, n, C, q.sims);

@@ -593,11 +593,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
 
 static int launch_pingpong(const GemmBf16Args& a, int vec, hipStream_t s) {
   const size_t lds = 2 * (256 + 256) * BK * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pingpong), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_pingpong), lds));
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   hipLaunchKernelGGL(gemm_bf16_pingpong, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, vec);
@@ -743,11 +739,7 @@ template <int ABLATE>
 static int launch_pp32(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
   auto kern = gemm_bf16_pp32<ABLATE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, 1);
@@ -982,14 +974,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 
 static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
-  static bool attr_set = false;
-  static int n_cu = 256;
-  if (!attr_set) {
-    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_persist), lds));
+  const int n_cu = device_cu_count();
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
@@ -997,18 +983,14 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   return SG_OK;
 }
 
-static int g_gemm_config = -1;                             // -1 = pick per shape
+static thread_local int g_gemm_config = -1;                // -1 = pick per shape (tuning override, per calling thread)
 void set_gemm_config(int c) { g_gemm_config = c; }
 
 template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false>
 static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
   auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8>;
   const size_t lds = (size_t)STAGES * (BM_ + BN_) * BKT * 2;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.batch), dim3(WM * WN * 64), lds, s, a, a.act, a.c_is_bf16, vec);

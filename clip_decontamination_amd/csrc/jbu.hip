@@ -446,7 +446,7 @@ __global__ void scale_kernel(float* p, float a, int64_t n) {
 
 extern "C" int sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim) {
   SG_REQUIRE(out && (kind == 0 || kind == 1) && feat_dim > 0 && feat_dim % 4 == 0, "sg_jbu_create: bad arguments (kind 0 = jbu_one, 1 = jbu_stack; feat_dim %% 4 == 0)");
-  SG_HIP(hipSetDevice(device));
+  DeviceGuard dg(device);
   sg_jbu* j = new sg_jbu();
   j->device = device; j->kind = kind; j->C = feat_dim; j->n_stage_sets = kind == 0 ? 1 : 4;
   const int r = kind == 0 ? 5 : 3;                     // JBUOne radius 5, JBUStack radius 3 (upsamplers.py:281-284,308)
@@ -485,6 +485,7 @@ extern "C" void sg_jbu_destroy(sg_jbu* j) {
 
 extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, int64_t numel, sg_stream st) {
   SG_REQUIRE(j && name && src, "sg_jbu_set_tensor: null argument");
+  DeviceGuard dg(j->device);
   hipStream_t s = as_stream(st);
   auto put = [&](float* dst, int64_t n) -> int {
     SG_REQUIRE(numel == n, "sg_jbu_set_tensor(%s): expected %lld elements, got %lld", name, (long long)n, (long long)numel);
@@ -561,6 +562,7 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
                                float* out, void* ws, size_t ws_bytes, sg_stream st) {
   SG_REQUIRE(j && source && guidance && out && ws, "sg_jbu_upsample: null argument");
   for (size_t i = 0; i < j->have.size(); ++i) if (!j->have[i]) return fail(SG_ERR_STATE, "sg_jbu_upsample: upsampler weights incomplete");
+  DeviceGuard dg(j->device);
   hipStream_t s = as_stream(st);
   JbuPlan p;
   const size_t need = jbu_plan(j, B, gh, gw, ws, false, p);
@@ -586,11 +588,7 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
     {
       const int WT = AC_T + 2 * r;
       const size_t lds = (size_t)WT * WT * JK_LD * sizeof(float);
-      static bool jk_attr = false;
-      if (!jk_attr) {
-        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jbu_kernel_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        jk_attr = true;
-      }
+      SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_tiled_kernel), 64 * 1024));
       SG_REQUIRE(lds <= 64 * 1024, "sg_jbu_upsample: window %d too large", d);
       hipLaunchKernelGGL(jbu_kernel_tiled_kernel, dim3((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B), dim3(256), lds, s, p.proj, p.gs, oh,
                          ow, r, S.range_temp, S.sigma, p.X, fast ? p.X16 : nullptr, KP1);
@@ -624,11 +622,7 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
       const int WT = AC_T + 2 * r, KP = (int)align_up((size_t)WT * WT, 32);
       const size_t lds = (size_t)(64 + ACM_CC) * (KP + 8) * sizeof(bf16_t);
       SG_REQUIRE(lds <= 160 * 1024, "sg_jbu_upsample: window %d needs %zu bytes of LDS", d, lds);
-      static bool attr_set = false;
-      if (!attr_set) {
-        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jbu_adaptive_conv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-      }
+      SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_adaptive_conv_mfma_kernel), 160 * 1024));
       dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
       hipLaunchKernelGGL(jbu_adaptive_conv_mfma_kernel, grid, dim3(256), lds, s, (const bf16_t*)p.hr, p.Kf, ldk, oh, ow, C, r, KP, dst,
                          (stg == 3 && C % 64 == 0) ? (bf16_t*)p.x16 : nullptr);

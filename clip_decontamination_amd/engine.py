@@ -97,15 +97,16 @@ class HipVisionTower:
     # -- weights -----------------------------------------------------------------------------------
     def load_state_dict(self, state_dict) -> None:
         """Keys as in the reference's ``net.visual.state_dict()`` (a ``visual.`` prefix is accepted)."""
-        s = stream_ptr()
-        for name, value in state_dict.items():
-            if name.startswith("visual."):
-                name = name[len("visual."):]
-            t = torch.as_tensor(value) if not torch.is_tensor(value) else value
-            t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
-            check(self.lib.sg_vit_set_tensor(self._ctx, name.encode(), ptr(t), t.numel(), s), f"sg_vit_set_tensor({name})")
-        torch.cuda.current_stream().synchronize()     # staging tensors may now be freed
-        check(self.lib.sg_vit_finalize(self._ctx, s), "sg_vit_finalize")
+        with torch.cuda.device(self.device):
+            s = stream_ptr(self.device)
+            for name, value in state_dict.items():
+                if name.startswith("visual."):
+                    name = name[len("visual."):]
+                t = torch.as_tensor(value) if not torch.is_tensor(value) else value
+                t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+                check(self.lib.sg_vit_set_tensor(self._ctx, name.encode(), ptr(t), t.numel(), s), f"sg_vit_set_tensor({name})")
+            torch.cuda.current_stream(self.device).synchronize()     # staging tensors may now be freed
+            check(self.lib.sg_vit_finalize(self._ctx, s), "sg_vit_finalize")
 
     # -- options --------------------------------------------------------------------------------------
     def forward_opts(self, model_type: str, ignore_residual: bool = True, apply_similarity_enhancement: bool = True) -> ForwardOpts:
@@ -151,6 +152,12 @@ class HipVisionTower:
                       scene_index: Optional[torch.Tensor] = None):
         """scene: f32 [3,H,W] / [B,3,H,W] normalised planes, or u8 [H,W,3] / [B,H,W,3] raw RGB.
         windows: int32 [T,4] (y1,y2,x1,x2) on the device.  Returns (cls [T,E] or None, tokens [T,gh*gw,E])."""
+        if scene.is_cuda and scene.device != self.device:
+            raise RuntimeError(f"scene lives on {scene.device}, the tower on {self.device}")
+        with torch.cuda.device(self.device):          # the tower's device, whatever the caller's current device is
+            return self._forward_tiles(scene, windows, tile_hw, opts, scene_index)
+
+    def _forward_tiles(self, scene, windows, tile_hw, opts, scene_index):
         if scene.dtype == torch.uint8:
             fmt = _lib.IMG_U8_NHWC
             H, W = scene.shape[-3], scene.shape[-2]
@@ -183,7 +190,7 @@ class HipVisionTower:
         tokens = torch.empty(T, gh * gw, E, dtype=torch.float32, device=self.device)
         need = self.lib.sg_vit_workspace_bytes(self._ctx, T, gh, gw, C.byref(opts))
         wp, wn = self._workspace(need)
-        check(self.lib.sg_vit_forward(self._ctx, C.byref(tb), C.byref(opts), ptr(cls), ptr(tokens), wp, wn, stream_ptr()),
+        check(self.lib.sg_vit_forward(self._ctx, C.byref(tb), C.byref(opts), ptr(cls), ptr(tokens), wp, wn, stream_ptr(self.device)),
               "sg_vit_forward")
         return cls, tokens
 
@@ -217,7 +224,7 @@ class HipTextTower:
         with torch.cuda.device(self.device):
             check(self.lib.sg_text_create(C.byref(self._ctx), self.device.index or 0, cfg.width, cfg.layers, cfg.heads, cfg.context_length,
                                           cfg.vocab_size, cfg.embed_dim, int(cfg.quick_gelu), self.precision), "sg_text_create")
-            s = stream_ptr()
+            s = stream_ptr(self.device)
             wanted = ("token_embedding.", "positional_embedding", "transformer.", "ln_final.", "text_projection")
             for name, value in state_dict.items():
                 if name.startswith("visual.") or not name.startswith(wanted):
@@ -225,7 +232,7 @@ class HipTextTower:
                 t = torch.as_tensor(value) if not torch.is_tensor(value) else value
                 t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
                 check(self.lib.sg_text_set_tensor(self._ctx, name.encode(), ptr(t), t.numel(), s), f"sg_text_set_tensor({name})")
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
 
     def __del__(self):
         ctx = getattr(self, "_ctx", None)
@@ -237,6 +244,8 @@ class HipTextTower:
         """text: int [S, context_length] token ids -> [S, E] f32."""
         if text.dim() != 2 or text.shape[1] != self.cfg.context_length:
             raise ValueError(f"token ids must be [S, {self.cfg.context_length}], got {tuple(text.shape)}")
+        if text.numel() and (int(text.min()) < 0 or int(text.max()) >= self.cfg.vocab_size):
+            raise IndexError(f"token id outside [0, {self.cfg.vocab_size}) (the reference's nn.Embedding raises too)")
         ids = text.to(device=self.device, dtype=torch.int32).contiguous()
         S = ids.shape[0]
         out = torch.empty(S, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
@@ -246,7 +255,7 @@ class HipTextTower:
             need = self.lib.sg_text_workspace_bytes(self._ctx, S)
             ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
             base = ws.data_ptr() + (-ws.data_ptr()) % 256
-            check(self.lib.sg_text_encode(self._ctx, ptr(ids), S, ptr(out), C.c_void_p(base), need, stream_ptr()), "sg_text_encode")
+            check(self.lib.sg_text_encode(self._ctx, ptr(ids), S, ptr(out), C.c_void_p(base), need, stream_ptr(self.device)), "sg_text_encode")
         return torch.nn.functional.normalize(out, dim=-1) if normalize else out
 
     def query_features(self, tokenizer, query_words: Sequence[str]) -> torch.Tensor:

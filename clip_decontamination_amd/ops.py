@@ -24,8 +24,25 @@ def ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """The caller's current stream ON ``device`` (default: the current device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_tensor_device(fn):
+    """Run an op on the device its first GPU tensor argument lives on: the context-free entry points launch on the CURRENT
+    device, so a tensor on cuda:1 in a process whose current device is cuda:0 must switch first (stream_ptr() then picks that
+    device's current stream)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if torch.is_tensor(a) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapper
 
 
 def precision_id(precision) -> int:
@@ -52,6 +69,7 @@ def _aligned(buf: torch.Tensor) -> Tuple[C.c_void_p, int]:
     return C.c_void_p(p + off), buf.numel() - off
 
 
+@on_tensor_device
 def linear(A, W, bias=None, residual=None, act: int = 0, precision="bf16"):
     """act(A @ W^T + bias) (+ residual); act 0 none / 1 QuickGELU / 2 erf-GELU."""
     lib = _lib.load()
@@ -70,6 +88,7 @@ def linear(A, W, bias=None, residual=None, act: int = 0, precision="bf16"):
     return out
 
 
+@on_tensor_device
 def quantize_rows_fp8(x):
     """f32 [rows, D] -> (uint8 e4m3 [rows, D], f32 scales [rows]); scale = max|row| / 448."""
     lib = _lib.load()
@@ -82,6 +101,7 @@ def quantize_rows_fp8(x):
     return q, sc
 
 
+@on_tensor_device
 def linear_fp8(A, W, bias=None, residual=None, act: int = 0, out_bf16: bool = False):
     """act(dequant(fp8(A) @ fp8(W)^T) + bias) (+ residual) on the fp8 MFMA path; A [M,K], W [N,K] f32, K % 128 == 0."""
     lib = _lib.load()
@@ -97,6 +117,7 @@ def linear_fp8(A, W, bias=None, residual=None, act: int = 0, out_bf16: bool = Fa
     return out, (a8, sa, w8, sw)
 
 
+@on_tensor_device
 def layernorm(x, gamma, beta, eps: float = 1e-5):
     lib = _lib.load()
     x, gamma, beta = _f32(x), _f32(gamma), _f32(beta)
@@ -107,6 +128,7 @@ def layernorm(x, gamma, beta, eps: float = 1e-5):
     return y
 
 
+@on_tensor_device
 def attention(qkv, heads: int, variant: str = "vanilla", sim=None, sim_weight: float = 1.0, precision="bf16",
               want_stats: bool = False):
     """Multi-term attention over packed qkv [B,N,3D] -> ctx [B,N,D] (+ head-averaged A[0,:], diag(A))."""
@@ -127,6 +149,7 @@ def attention(qkv, heads: int, variant: str = "vanilla", sim=None, sim_weight: f
     return (ctx, a_cls, a_diag) if want_stats else ctx
 
 
+@on_tensor_device
 def similarity_map(patches, temperature: float = 1.0, add_self_similarity: bool = True, precision="f32"):
     """patches [B,n,D] -> cosine self-similarity [B,n,n] (similarity_enhancement.py:37-66)."""
     lib = _lib.load()
@@ -141,6 +164,7 @@ def similarity_map(patches, temperature: float = 1.0, add_self_similarity: bool 
     return sim
 
 
+@on_tensor_device
 def outlier_suppress(feats, attn_cls, attn_diag, gh: int, gw: int, top_k: int = 10, contamination_temp: float = 0.1):
     """feats [B,gh*gw,D] (returns a refined copy) + the selected indices [B,k]."""
     lib = _lib.load()
@@ -157,6 +181,7 @@ def outlier_suppress(feats, attn_cls, attn_diag, gh: int, gw: int, top_k: int = 
     return feats, idx
 
 
+@on_tensor_device
 def weak_token_replace(feats, attn_diag, gh: int, gw: int, top_k: int = 10):
     lib = _lib.load()
     feats = _f32(feats).clone()
@@ -172,6 +197,7 @@ def weak_token_replace(feats, attn_diag, gh: int, gw: int, top_k: int = 10):
     return feats, idx
 
 
+@on_tensor_device
 def cosine_logits(tokens, cls, text, global_debias_factor: float = 0.0, cls_token_lambda: float = 0.0):
     """tokens [B,n,E], cls [B,E] or None, text [Q,E] -> logits [B,Q,n] (segmentor.py:309-336,374-386)."""
     lib = _lib.load()
@@ -186,6 +212,7 @@ def cosine_logits(tokens, cls, text, global_debias_factor: float = 0.0, cls_toke
     return out
 
 
+@on_tensor_device
 def stitch(tile_logits, windows, up_hw, pad_tl, canvas_hw):
     """tile_logits [T,Q,gh,gw]; windows int32 [T,4] (y1,y2,x1,x2) -> canvas [Q,H,W]."""
     lib = _lib.load()
@@ -200,6 +227,7 @@ def stitch(tile_logits, windows, up_hw, pad_tl, canvas_hw):
     return canvas
 
 
+@on_tensor_device
 def resize_bilinear(src, size):
     """[C,h,w] -> [C,H,W], align_corners=False."""
     lib = _lib.load()
@@ -212,6 +240,7 @@ def resize_bilinear(src, size):
     return dst
 
 
+@on_tensor_device
 def postprocess(logits, query_idx, num_classes: int, logit_scale: float, prob_thd: float, bg_idx: int, want_probs: bool = True):
     """logits [Q,H,W] -> (probs [K,H,W] or None, labels int64 [1,H,W]) (segmentor.py:475-489)."""
     lib = _lib.load()
@@ -226,6 +255,7 @@ def postprocess(logits, query_idx, num_classes: int, logit_scale: float, prob_th
     return probs, labels
 
 
+@on_tensor_device
 def render_maps(labels, probs, palette, want_mask: bool = True, want_heat: bool = True):
     """labels int64 [1,H,W] or [H,W], probs [K,H,W], palette uint8 [K,3] -> (mask uint8 [H,W,3] | None, heat uint8 [H,W,3] | None)."""
     lib = _lib.load()
@@ -241,6 +271,7 @@ def render_maps(labels, probs, palette, want_mask: bool = True, want_heat: bool 
     return mask, heat
 
 
+@on_tensor_device
 def adaptive_conv(inp, filters):
     """FeatUp AdaptiveConv.apply: inp [B,C,h+d-1,w+d-1], filters [B,h,w,d,d] -> [B,C,h,w]."""
     lib = _lib.load()
@@ -253,6 +284,7 @@ def adaptive_conv(inp, filters):
     return out
 
 
+@on_tensor_device
 def cross_tile_fusion(tokens, hg: int, wg: int, gh: int, gw: int, boundary_width: int = 2, fusion_mode: str = "weighted",
                       fusion_strength: float = 0.3):
     """tokens [hg*wg, gh*gw, C] (tiles in raster order) -> fused copy (reference cross_tile_fusion.py, B=1 tile-by-tile semantics)."""
@@ -268,6 +300,7 @@ def cross_tile_fusion(tokens, hg: int, wg: int, gh: int, gw: int, boundary_width
     return tokens
 
 
+@on_tensor_device
 def global_debias(tokens, cls, factor: float):
     """tokens - cls_hat * (cos(tokens, cls_hat) * factor)  (segmentor.py:322-336); cls is normalised inside."""
     lib = _lib.load()
@@ -279,6 +312,7 @@ def global_debias(tokens, cls, factor: float):
     return out
 
 
+@on_tensor_device
 def ctd_debias(tokens, cls, eps: float = 1.1, min_samples: int = 11, factor: float = -1.5, want_labels: bool = True, normalize_cls: bool = False):
     """Cluster-Then-Debias (segmentor.py:339-365): tokens [B,n,C], CLS features [B,C] (unit unless ``normalize_cls``) ->
     (debiased copy, labels int32 [B,n])."""
@@ -310,6 +344,7 @@ class CrossTileSteps:
     def strip_len(self, which: int) -> int:
         return self.gh * self.bw if which == 0 else self.bw * self.gw
 
+    @on_tensor_device
     def pack(self, tokens, tile0: int, which: int, left_result=None):
         _require_gpu(tokens, left_result)
         out = torch.empty(tokens.shape[0], self.strip_len(which), self.C, dtype=torch.float32, device=tokens.device)
@@ -317,6 +352,7 @@ class CrossTileSteps:
                                           which, ptr(out), stream_ptr()), "sg_cross_tile_pack")
         return out
 
+    @on_tensor_device
     def fuse(self, tokens, tile0: int, nbr_strips, which: int):
         _require_gpu(tokens, nbr_strips)
         res = torch.zeros(tokens.shape[0], self.strip_len(which), self.C, dtype=torch.float32, device=tokens.device)
@@ -324,6 +360,7 @@ class CrossTileSteps:
                                           self.mode, self.strength, which, ptr(res), stream_ptr()), "sg_cross_tile_fuse")
         return res
 
+    @on_tensor_device
     def apply(self, tokens, tile0: int, left_result, top_result):
         _require_gpu(tokens, left_result, top_result)
         check(self.lib.sg_cross_tile_apply(ptr(tokens), ptr(left_result), ptr(top_result), tokens.shape[0], tile0, self.wg, self.gh, self.gw,

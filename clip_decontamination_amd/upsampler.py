@@ -35,7 +35,8 @@ class HipJBU:
         self.device = torch.device(device)
         self.precision = min(precision_id(precision), 1)          # the upsampler has no fp8 path: fp8 towers feed it in bf16 mode
         self._ctx = C.c_void_p()
-        self._ws = None
+        self._ws = {}
+        self.tiles_per_launch = 8            # tiles per JBU launch (workspace ~2.2 GB per 512-pixel tile)
         with torch.cuda.device(self.device):
             check(self.lib.sg_jbu_create(C.byref(self._ctx), self.device.index or 0, KINDS[model_name], feat_dim), "sg_jbu_create")
 
@@ -59,19 +60,23 @@ class HipJBU:
         return up
 
     def load_state_dict(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True):
-        s = stream_ptr()
-        for name, value in state_dict.items():
-            t = torch.as_tensor(value).detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
-            check(self.lib.sg_jbu_set_tensor(self._ctx, name.encode(), ptr(t), t.numel(), s), f"sg_jbu_set_tensor({name})")
-        torch.cuda.current_stream().synchronize()
+        with torch.cuda.device(self.device):
+            s = stream_ptr(self.device)
+            for name, value in state_dict.items():
+                t = torch.as_tensor(value).detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+                check(self.lib.sg_jbu_set_tensor(self._ctx, name.encode(), ptr(t), t.numel(), s), f"sg_jbu_set_tensor({name})")
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes + 256:
-            self._ws = None
-            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
-        p = self._ws.data_ptr()
+        """One arena per stream (as HipVisionTower._workspace): launches on different streams may overlap and must not share scratch."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes + 256:
+            self._ws[key] = None
+            ws = self._ws[key] = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        p = ws.data_ptr()
         off = (-p) % 256
-        return C.c_void_p(p + off), self._ws.numel() - off
+        return C.c_void_p(p + off), ws.numel() - off
 
     def __call__(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
         """Reference call shape: source [B,C,h,w], guidance [B,3,H,W] -> [B,C,16h,16w] (upsamplers.py:278-325)."""
@@ -86,17 +91,19 @@ class HipJBU:
         guidance = guidance.contiguous().float()
         B, n, Cc = tokens.shape
         assert n == gh * gw and Cc == self.feat_dim
-        out = torch.empty(B, 256 * n, Cc, dtype=torch.float32, device=self.device)
-        need = self.lib.sg_jbu_workspace_bytes(self._ctx, B, gh, gw)
-        wp, wn = self._workspace(need)
-        check(self.lib.sg_jbu_upsample(self._ctx, ptr(tokens), ptr(guidance), B, gh, gw, guidance.shape[-2], guidance.shape[-1],
-                                       self.precision, ptr(out), wp, wn, stream_ptr()), "sg_jbu_upsample")
+        with torch.cuda.device(self.device):
+            out = torch.empty(B, 256 * n, Cc, dtype=torch.float32, device=self.device)
+            need = self.lib.sg_jbu_workspace_bytes(self._ctx, B, gh, gw)
+            wp, wn = self._workspace(need)
+            check(self.lib.sg_jbu_upsample(self._ctx, ptr(tokens), ptr(guidance), B, gh, gw, guidance.shape[-2], guidance.shape[-1],
+                                           self.precision, ptr(out), wp, wn, stream_ptr(self.device)), "sg_jbu_upsample")
         return out
 
     def logits(self, tokens, cls, scene, windows, tile_hw, pad_lt, grid, text, global_debias_factor, cls_token_lambda, scene_index=None,
                padded_hw=None):
         """Per-pixel logits [T, Q, 16gh, 16gw] for the tiles of one launch: global debias -> JBU -> cosine logits
-        (reference order, segmentor.py:317-379).  One tile at a time: the C x S^2 feature map is 0.5 GB at 512^2."""
+        (reference order, segmentor.py:317-379; the reference runs B=1, :369-372).  ``tiles_per_launch`` tiles go through the
+        upsampler per launch -- no per-tile host loop; the chunk bounds the workspace (C x S^2 f32 = 0.5 GB per 512-pixel tile)."""
         T = tokens.shape[0]
         gh, gw = grid
         th, tw = tile_hw
@@ -107,26 +114,28 @@ class HipJBU:
         scene = scene.contiguous()
         H, W = (scene.shape[-3], scene.shape[-2]) if fmt == _lib.IMG_U8_NHWC else (scene.shape[-2], scene.shape[-1])
         Q = text.shape[0]
-        if cls is not None and global_debias_factor != 0:
-            deb = torch.empty_like(tokens)
-            check(self.lib.sg_global_debias(ptr(tokens), ptr(cls), T, tokens.shape[1], tokens.shape[2], float(global_debias_factor),
-                                            ptr(deb), stream_ptr()), "sg_global_debias")
-            tokens = deb
-        outs = []
-        windows = windows.to(device=self.device, dtype=torch.int32).contiguous()
-        for i in range(T):
-            tb = TileBatch()
-            tb.scene, tb.format, tb.scene_h, tb.scene_w = scene.data_ptr(), fmt, H, W
-            wi = windows[i:i + 1].contiguous()
-            tb.windows = wi.data_ptr()
+        with torch.cuda.device(self.device):
+            if cls is not None and global_debias_factor != 0:
+                tokens = ops.global_debias(tokens, cls, float(global_debias_factor))
+            outs = []
+            windows = windows.to(device=self.device, dtype=torch.int32).contiguous()
             if scene_index is not None:
-                si = scene_index[i:i + 1].to(device=self.device, dtype=torch.int32).contiguous()
-                tb.scene_index = si.data_ptr()
-                tb.scene_stride = 3 * H * W
-            tb.n_tiles, tb.tile_h, tb.tile_w, tb.pad_l, tb.pad_t, tb.grid_h, tb.grid_w = 1, th, tw, l, t, gh, gw
-            guid = torch.empty(1, 3, ph, pw, dtype=torch.float32, device=self.device)
-            check(self.lib.sg_extract_tiles(C.byref(tb), ph, pw, ptr(guid), stream_ptr()), "sg_extract_tiles")
-            feats = self.upsample_tokens(tokens[i:i + 1], guid, gh, gw)                      # [1, 256 n, C]
-            lg = ops.cosine_logits(feats, None if cls is None else cls[i:i + 1], text, 0.0, cls_token_lambda if cls is not None else 0.0)
-            outs.append(lg.reshape(1, Q, 16 * gh, 16 * gw))
-        return torch.cat(outs, 0)
+                scene_index = scene_index.to(device=self.device, dtype=torch.int32).contiguous()
+            step = max(1, int(self.tiles_per_launch))
+            for i in range(0, T, step):
+                c = min(step, T - i)
+                tb = TileBatch()
+                tb.scene, tb.format, tb.scene_h, tb.scene_w = scene.data_ptr(), fmt, H, W
+                wi = windows[i:i + c].contiguous()
+                tb.windows = wi.data_ptr()
+                if scene_index is not None:
+                    si = scene_index[i:i + c].contiguous()
+                    tb.scene_index = si.data_ptr()
+                    tb.scene_stride = 3 * H * W
+                tb.n_tiles, tb.tile_h, tb.tile_w, tb.pad_l, tb.pad_t, tb.grid_h, tb.grid_w = c, th, tw, l, t, gh, gw
+                guid = torch.empty(c, 3, ph, pw, dtype=torch.float32, device=self.device)
+                check(self.lib.sg_extract_tiles(C.byref(tb), ph, pw, ptr(guid), stream_ptr(self.device)), "sg_extract_tiles")
+                feats = self.upsample_tokens(tokens[i:i + c], guid, gh, gw)                      # [c, 256 n, C]
+                lg = ops.cosine_logits(feats, None if cls is None else cls[i:i + c], text, 0.0, cls_token_lambda if cls is not None else 0.0)
+                outs.append(lg.reshape(c, Q, 16 * gh, 16 * gw))
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]

@@ -12,7 +12,10 @@
  *     that takes a stream;
  *   - every call returns 0 on success or a negative sg_status; the message of the last
  *     failure on the calling thread is returned by sg_last_error(); nothing aborts or throws;
- *   - calls are asynchronous on the given stream and re-entrant across contexts.
+ *   - calls are asynchronous on the given stream and re-entrant across contexts: the library keeps no mutable per-process
+ *     state (per-device launch bookkeeping is keyed by device and thread-safe; the measurement and tuning hooks below act on
+ *     the calling thread only); an entry point that takes a context makes the context's device current for its duration, the
+ *     context-free ops run on the caller's current device (the one the stream belongs to).
  *   - "tokens" are token-major [B, N, D] row-major (N = 1 + gh*gw, CLS first).
  */
 #ifndef SEGEARTH_HIP_H
@@ -111,10 +114,10 @@ int sg_version(void);
  * HIP events bracket every launch of a kernel family on the stream it is launched on.
  * category: 0 = bf16 MFMA GEMM (small-shape tile variants), 1 = fused attention, 2 = f32 MFMA GEMM,
  *           3 = the persistent bf16 GEMM (every large ViT linear; the kernel bench.py's roofline prices), 4 = fp8 GEMM.
- *           Read after synchronising. */
+ *           Read after synchronising.  The state belongs to the calling thread (enable, launch and read on one thread). */
 int sg_profile_enable(int capacity);
 int sg_profile_disable(void);
-int sg_set_gemm_config(int cfg);   /* tuning hook: bf16 GEMM tile variant, -1 = automatic */
+int sg_set_gemm_config(int cfg);   /* tuning hook (calling thread only): bf16 GEMM tile variant, -1 = automatic */
 int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped);
 
 /* ---- context and weights ------------------------------------------------------------------
@@ -238,7 +241,9 @@ int sg_ctd_debias(float* tokens, const float* cls, int B, int n, int C, double e
  * sg_text_encode replaces CLIP.encode_text(tokens) (open_clip/model.py:288-306): token + positional embedding, causal
  * residual blocks, ln_final, EOT pooling (argmax of the ids), @ text_projection.  Tensor names = the text part of the CLIP
  * state dict ("token_embedding.weight", "positional_embedding", "transformer.resblocks.N.*", "ln_final.*", "text_projection").
- *   tokens int32 [n_seq, context_length] -> out [n_seq, E] f32 (not normalised). */
+ *   tokens int32 [n_seq, context_length] -> out [n_seq, E] f32 (not normalised).  Init-time call: unlike the rest of the ABI it
+ *   synchronises the stream before returning, so that an id outside [0, vocab_size) is SG_ERR_INVALID (the reference's
+ *   nn.Embedding raises) instead of a silently clamped row. */
 typedef struct sg_text sg_text;
 int  sg_text_create(sg_text** out, int device, int width, int layers, int heads, int context_length, int vocab_size, int embed_dim,
                     int quick_gelu, int precision);
