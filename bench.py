@@ -55,8 +55,10 @@ def build_pipeline(device, precision, tiles_per_launch):
     return cfg, pipe
 
 
-def cpu_baseline(cfg, n_tiles=3):
-    """The oracle (port of the reference path, fp32, torch CPU) on a bounded sample of the same workload."""
+def cpu_baseline(cfg, n_tiles=3, keep=None):
+    """The oracle (port of the reference path, fp32, torch CPU) on a bounded sample of the same workload.  ``keep`` (a list)
+    receives (tile, oracle logits [Q,512,512], oracle labels) of the timed tiles, so the same tiles can be pushed through the HIP
+    path and compared (the `parity` object of the bench line)."""
     from oracle import segment as OS, vit as OV
     try:
         avail = len(os.sched_getaffinity(0))
@@ -74,7 +76,10 @@ def cpu_baseline(cfg, n_tiles=3):
         o.postprocess(o.forward_slide(tiles[:1])[0])                  # warm-up tile
         t0 = time.perf_counter()
         for i in range(1, n_tiles + 1):
-            o.postprocess(o.forward_slide(tiles[i:i + 1])[0])
+            lg = o.forward_slide(tiles[i:i + 1])[0]
+            _, lab = o.postprocess(lg)
+            if keep is not None:
+                keep.append((tiles[i], lg, lab))
         dt = time.perf_counter() - t0
     return {"value": n_tiles * TILE * TILE / dt / 1e6, "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n_tiles} tiles of {TILE}x{TILE} after 1 warm-up, {dt / n_tiles:.2f} s/tile, fp32 torch CPU"}
@@ -160,8 +165,11 @@ def main():
             part.record_stream(cur)
         return torch.cat(parts, 0)
 
+    last = {}
+
     def step():
         tl = tower()                                                  # [tiles of this rank, Q, 37, 37]
+        last["tl"] = tl
         if world > 1:
             gathered = [torch.empty_like(tl) for _ in range(world)]
             dist.all_gather(gathered, tl)                             # RCCL over xGMI: 44 kB per tile
@@ -212,6 +220,23 @@ def main():
         except (OSError, ValueError):
             return None, None
 
+    # ---- correctness of the TIMED launch shape (outside the timed region) --------------------------------------------------
+    # (a) first / middle / last tile of this rank recomputed ALONE (one-tile launches) must equal their rows of the batched launch
+    def self_check():
+        tl = last["tl"]
+        picks = sorted({0, len(my_local) // 2, len(my_local) - 1})
+        worst, exact = 0.0, True
+        for i in picks:
+            alone = pipe.tile_logits(slab, [my_local[i]], (TILE, TILE))[0]
+            d = (alone - tl[i]).abs().max().item()
+            worst = max(worst, d)
+            exact = exact and bool(torch.equal(alone, tl[i]))
+        if not (worst < 1e-3):
+            raise SystemExit(f"bench self-check FAILED: a tile of the {len(my_local)}-tile launch differs from the same tile run alone by {worst}")
+        return {"tiles_checked": len(picks), "max_dlogit_batched_vs_alone": worst, "bit_identical": exact}
+
+    batched_check = self_check()
+
     tiles_total = len(wins) * args.steps
     value = tiles_total * TILE * TILE / dt / 1e6
     if rank == 0:
@@ -241,8 +266,21 @@ def main():
                          "share_of_step_time": {"gemm_bf16_persist": round(g_ms / (dt * 1e3), 4), "other_bf16_gemm": round(o_ms / (dt * 1e3), 4),
                                                 "attention": round(a_ms / (dt * 1e3), 4)}},
         }
+        out["self_check"] = batched_check
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            kept = []
+            out["cpu_baseline"] = cpu_baseline(cfg, keep=kept)
+            # (b) the CPU-baseline tiles through the HIP path (same precision mode as the timed run): logits vs the oracle's
+            worst, agree, npx = 0.0, 0, 0
+            for tile, lg_ref, lab_ref in kept:
+                lg = pipe.forward_slide(tile.to(device), STRIDE, TILE)[0]
+                _, lab = pipe.postprocess(lg, want_probs=False)
+                worst = max(worst, (lg.cpu() - lg_ref).abs().max().item())
+                agree += int((lab.cpu() == lab_ref).sum())
+                npx += lab_ref.numel()
+            out["parity"] = {"max_dlogit": worst, "label_agreement": agree / max(npx, 1), "n_tiles": len(kept),
+                             "against": "oracle (fp32 CPU restatement pinned to the reference), the cpu_baseline tiles, per-pixel logits after stitch",
+                             "mode": args.precision}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

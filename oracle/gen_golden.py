@@ -3,7 +3,7 @@
 deterministic synthetic weights and inputs.  Runs only in the build container; the fixtures are
 data (inputs' seeds + expected outputs), never reference source.
 
-    python -m oracle.gen_golden [--only tiny|refine|jbu|segment|text|ctd|real]
+    python -m oracle.gen_golden [--only tiny|refine|jbu|jbu_real|segment|text|ctd|real]
 
 Every fixture is cross-checked here against the build's own CPU restatement (oracle/*.py) so a
 drift between the two fails at mint time, and again in tests/test_oracle_vs_golden.py.
@@ -304,6 +304,38 @@ def gen_jbu():
     save("jbu", **out)
 
 
+def gen_jbu_real():
+    """The reference's JBUStack (dim 512) on the TRAINED COCO-Stuff checkpoint it ships (simfeatup_dev/weights/, loaded as at
+    segmentor.py:281-283 but with weights_only=True): real range_temp / sigma_spatial / fixup weights exercise the clamp and
+    softmax regimes synthetic weights do not (upsamplers.py:230-275).  The fixture stores the weights (data) + input + output."""
+    print("[jbu_real] JBUStack(512) with the shipped clip_jbu_stack_cocostuff.ckpt")
+    U = R.ref("simfeatup_dev.upsamplers")
+    U.AdaptiveConv = type("AC", (), {"apply": staticmethod(U.adaptive_conv_py_simple)})
+    ck = torch.load("/root/reference/simfeatup_dev/weights/clip_jbu_stack_cocostuff.ckpt", map_location="cpu", weights_only=True)["state_dict"]
+    sd = {k[10:]: v.float() for k, v in ck.items() if k.startswith("upsampler.")}
+    C, gs = 512, 4
+    up = U.get_upsampler("jbu_stack", C)
+    up.load_state_dict(sd, strict=True)
+    up.eval()
+    g = torch.Generator().manual_seed(21)
+    src = torch.randn(1, C, gs, gs, generator=g)
+    S = gs * 16
+    low = torch.randn(1, 3, 5, 5, generator=g)
+    guid = F.interpolate(low, size=(S, S), mode="bicubic", align_corners=False) + 0.3 * torch.randn(1, 3, S, S, generator=g)
+    with torch.no_grad():
+        r = up(src, guid)
+        o = OJ.jbu_forward(sd, src, guid)
+        close(o, r, 2e-4 * float(r.abs().max()), "jbu_stack real weights end-to-end")
+        small = F.adaptive_avg_pool2d(guid, (gs * 2, gs * 2))
+        k_ref = up.up1.get_range_kernel(small)
+        close(OJ.range_kernel(sd, "up1", small, OJ.radius_of(sd, "up1")), k_ref, 1e-5, "real range kernel")
+    print("    range_temp:", [float(sd[f"up{i}.range_temp"]) for i in range(1, 5)], " sigma:", [float(sd[f"up{i}.sigma_spatial"]) for i in range(1, 5)])
+    # the [1,512,64,64] output is 8 MB: keep the first 64 channels in full and, over ALL channels, two per-pixel moments
+    out = {"src": src, "guidance": guid, "out_c64": r[0, :64], "out_sum": r[0].sum(0), "out_sq": (r[0] * r[0]).sum(0), "range1": k_ref}
+    out.update({"w." + k: v for k, v in sd.items()})
+    save("jbu_real", **out)
+
+
 # ---------------------------------------------------------------------------------------------
 POTSDAM_QIDX = [0, 0, 1, 2, 3, 4, 5, 5]          # configs/cls_potsdam.txt: 8 queries -> 6 classes
 
@@ -477,7 +509,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    steps = {"tiny": gen_tiny, "refine": gen_refine, "jbu": gen_jbu, "segment": gen_segment, "text": gen_text, "ctd": gen_ctd, "real": gen_real}
+    steps = {"tiny": gen_tiny, "refine": gen_refine, "jbu": gen_jbu, "jbu_real": gen_jbu_real, "segment": gen_segment, "text": gen_text, "ctd": gen_ctd, "real": gen_real}
     for k, fn in steps.items():
         if not a.only or a.only == k:
             fn()

@@ -43,6 +43,34 @@ def test_tile_result_does_not_depend_on_its_batch_or_position(pipe):
     assert torch.equal(pipe.tile_logits(scene, [wins[5]], (512, 512)), alone)
 
 
+def test_bench_launch_shape_128_tiles_equals_single_tile_launches(pipe):
+    """The headline launch shape: 128 L/14 tiles in ONE launch of the tower (R = 175 360 rows; every persistent GEMM workgroup
+    streams ~32 output tiles through the cur/nxt hand-off, re-stagger and patch-in-ring-slot path).  A handful of its tiles must
+    equal the same tiles run alone."""
+    from clip_decontamination_amd.pipeline import tile_windows
+    H, W = 256 * 7 + 512, 256 * 15 + 512                          # bench.py's scene band: 8 x 16 windows of 512 at stride 256
+    scene = torch.from_numpy(np.ascontiguousarray(Wt.make_tiles_u8(1, W, seed=1234, smooth=True)[0][:H, :W])).to(DEV)
+    wins = tile_windows(H, W, (256, 256), (512, 512))
+    assert len(wins) == 128
+    old = pipe.tiles_per_launch
+    try:
+        pipe.tiles_per_launch = 128
+        batched = pipe.tile_logits(scene, wins, (512, 512))
+        assert batched.shape == (128, len(QIDX), 37, 37) and torch.isfinite(batched).all()
+        worst = 0.0
+        for i in (0, 37, 64, 101, 127):
+            alone = pipe.tile_logits(scene, [wins[i]], (512, 512))[0]
+            d = (batched[i] - alone).abs().max().item()
+            worst = max(worst, d)
+            assert d < 1e-3, (i, d)
+            assert (batched[i].argmax(0) == alone.argmax(0)).float().mean().item() > 0.999, i
+        print(f"128-tile launch vs single-tile launches: max|dlogit| = {worst:.3e}")
+        again = pipe.tile_logits(scene, wins, (512, 512))
+        assert torch.equal(again, batched)                         # deterministic at the bench launch shape
+    finally:
+        pipe.tiles_per_launch = old
+
+
 def test_stitch_is_a_partition_of_unity_and_postprocess_is_well_formed(pipe):
     from clip_decontamination_amd import ops
     from clip_decontamination_amd.pipeline import tile_windows
@@ -89,3 +117,44 @@ def test_two_streams_do_not_share_scratch(pipe):
         cur.wait_stream(s1); cur.wait_stream(s2)
         a.record_stream(cur); b.record_stream(cur)
         assert torch.equal(a, ref_a) and torch.equal(b, ref_b)
+
+
+def test_two_contexts_on_two_host_threads():
+    """include/segearth_hip.h: "re-entrant across contexts".  Two towers (two sg_context), each driven from its own host thread on
+    its own stream, first launches racing (the per-device LDS opt-in bookkeeping is taken under a lock, the measurement / tuning
+    state is per thread): results equal the same forwards run one after the other."""
+    import threading
+    from clip_decontamination_amd.engine import HipVisionTower
+    cfg = Wt.vit_config("ViT-B-16")
+    w = Wt.make_vit_weights(cfg, seed=0)
+    towers = [HipVisionTower(cfg, w, precision="bf16", device=DEV) for _ in range(2)]
+    tiles = torch.from_numpy(Wt.make_tiles_u8(8, 224, seed=21, smooth=True)).to(DEV)            # R = 8 * 197 rows: the persistent GEMM path
+    win = torch.tensor([[0, 224, 0, 224]] * 8, dtype=torch.int32)
+    idx = torch.arange(8, dtype=torch.int32)
+    want = []
+    for t in towers:
+        c, tok = t.forward_tiles(tiles, win, (224, 224), t.forward_opts("SegEarth", True), idx)
+        want.append((c.clone(), tok.clone()))
+    torch.cuda.synchronize()
+    got, errs = [None, None], []
+
+    def run(i):
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                for _ in range(4):
+                    c, tok = towers[i].forward_tiles(tiles, win, (224, 224), towers[i].forward_opts("SegEarth", True), idx)
+                st.synchronize()
+                got[i] = (c.clone(), tok.clone())
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(got[i][0], want[i][0]) and torch.equal(got[i][1], want[i][1]), i

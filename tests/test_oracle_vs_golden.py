@@ -148,6 +148,19 @@ def test_jbu(golden, name):
     assert maxdiff(OJ.adaptive_conv(t(g["ac_in"]), t(g["ac_filt"])), g["ac_out"]) < 1e-5
 
 
+def test_jbu_on_the_trained_checkpoint(golden):
+    """JBUStack(512) on the COCO-Stuff weights the reference ships (fixture minted by oracle.gen_golden --only jbu_real from the
+    reference module + its own checkpoint): trained range_temp / sigma_spatial / fixup weights."""
+    g = golden("jbu_real")
+    w = {k[2:]: t(v) for k, v in g.items() if k.startswith("w.")}
+    with torch.no_grad():
+        out = OJ.jbu_forward(w, t(g["src"]), t(g["guidance"]))[0]
+    scale = float(np.abs(g["out_c64"]).max())
+    assert maxdiff(out[:64], g["out_c64"]) < 2e-4 * scale
+    assert maxdiff(out.sum(0), g["out_sum"]) < 2e-4 * float(np.abs(g["out_sum"]).max()) + 1e-3
+    assert maxdiff((out * out).sum(0), g["out_sq"]) < 2e-4 * float(np.abs(g["out_sq"]).max())
+
+
 CASES = {
     "ex_base": dict(model_type="Experimental", global_debias_factor=0.2, similarity_cfg=SIM, outlier_cfg=dict(top_k=6),
                     prob_thd=0.1, bg_idx=5, slide_crop=32, slide_stride=16),
