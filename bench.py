@@ -91,8 +91,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8"],
-                    help="bf16 = the headline configuration; fp8 = ordinary-block linears on fp8 MFMA (reported separately, never the default)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32", "fp8"],
+                    help="bf16 = the headline configuration; f16 = IEEE f16 operands at the same MFMA rate (the reference's own GPU arithmetic); "
+                         "f32 = parity mode; fp8 = ordinary-block linears on fp8 MFMA (reported separately, never the default)")
     ap.add_argument("--tile-cols", type=int, default=TILE_COLS, help="tiles per scene row")
     ap.add_argument("--tile-rows", type=int, default=TILE_ROWS_PER_RANK, help="tile rows per rank (weak scaling: the scene grows with the ranks)")
     ap.add_argument("--tiles-per-launch", type=int, default=0, help="0 = all of a rank's tiles in one launch of the tower")

@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsegearth_hip.so")
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "rowops.hip", "patchify.hip", "refine.hip",
+SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "attention_f16.hip", "rowops.hip", "patchify.hip", "refine.hip",
            "head.hip", "jbu.hip", "ctd.hip"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
@@ -42,7 +42,12 @@ def _newest_header() -> float:
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     sp = os.path.join(CSRC, src)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), _newest_header()):
+    newest = max(os.path.getmtime(sp), _newest_header())
+    with open(sp) as f:                               # a unit that re-compiles another .hip (attention_f16.hip) depends on it too
+        for line in f:
+            if line.startswith('#include "') and line.rstrip().endswith('.hip"'):
+                newest = max(newest, os.path.getmtime(os.path.join(CSRC, line.split('"')[1])))
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj
     cmd = [hipcc(), *FLAGS, "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)

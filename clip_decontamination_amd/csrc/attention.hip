@@ -11,9 +11,20 @@
 // the B operand of the next MFMA (accumulator-as-operand, k order (j&3)+8(j>>2)+4h), which computes
 // O^T = V^T.P^T with V^T fragments fetched by ds_read_b64_tr_b16 (hardware transpose) from a
 // row-major V tile.  O^T keeps the query on the lane, so the online-softmax rescale is lane-local.
+// This file is compiled TWICE: as is (bf16 operands, the kernels + attention_bf16 + the statistics kernels) and through
+// attention_f16.hip with SG_ATTN_F16 = 1 (IEEE f16 operands on the v_mfma_*_f16 forms: same cycles, 3 more mantissa bits --
+// the reference's own GPU arithmetic, SG_PREC_F16), which adds attention_f16_impl.  The operand kind is a template parameter of
+// the kernels, so the two translation units instantiate different symbols.
 #include "rowops.h"
 
+#ifndef SG_ATTN_F16
+#define SG_ATTN_F16 0
+#endif
+
 namespace sg {
+
+constexpr bool AF16 = SG_ATTN_F16 != 0;
+int attention_f16_impl(const AttnArgs& a, hipStream_t s);      // defined by the SG_ATTN_F16 translation unit
 
 constexpr int QB = 128;        // queries per workgroup
 constexpr int KT = 64;         // keys per LDS tile
@@ -62,7 +73,7 @@ __device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u
 // MULTI = several separately soft-maxed streams are summed (SCLIP / SegEarth / GEM); otherwise no second accumulator.
 // Lean variants are capped at 256 registers (VGPR-form MFMA, 2+ waves per SIMD); the register-hungry ones (bias + multi-stream,
 // head_dim > 64) may take the whole file rather than spill.
-template <int DH, int TS, bool GENERIC, bool MULTI>
+template <int DH, int TS, bool GENERIC, bool MULTI, bool F16>
 __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC || MULTI || DH > 80))) ? 1 : 2) void attn_kernel(AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,9 +137,17 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 #pragma unroll
       for (int t = 0; t < TS; ++t)
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks)
+        for (int ks = 0; ks < C::KS; ++ks) {
+          if constexpr (F16) {
+            f16x8 hq = __builtin_bit_cast(f16x8, qf[t][ks]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) qf[t][ks][j] = (__bf16)((float)qf[t][ks][j] * c2);
+            for (int j = 0; j < 8; ++j) hq[j] = (_Float16)((float)hq[j] * c2);
+            qf[t][ks] = __builtin_bit_cast(bf16x8, hq);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[t][ks][j] = (__bf16)((float)qf[t][ks][j] * c2);
+          }
+        }
     }
     // Retire the Q loads HERE: otherwise the compiler's counted vmcnt in front of the first QK^T MFMA also waits (every iteration)
     // for the K/V prefetch that was issued a few instructions earlier, exposing its full latency.
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
           for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)              // the two key sub-blocks alternate: no MFMA waits on its predecessor
-              sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][t][ks], qf[t][ks], sacc[sub], 0, 0, 0);
+              sacc[sub] = mfma_32x32x16<F16>(kf[sub][t][ks], qf[t][ks], sacc[sub]);
       }
       // (b) V^T fragments of the tile are fetched NOW (transposed LDS reads, lane 4q+p of a 16-lane group addresses row q,
       // cols 4p..4p+3) so their latency hides under the softmax arithmetic below.
@@ -292,17 +311,25 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
       lsum += __shfl_xor(lsum, 32, 64);
       l_run += lsum;
       // P (bf16) is already the B operand: element j of k-step s2 of sub-block sub = sc[16 sub + 8 s2 + j]
-      bf16x8 pf[4];
+      bf16x8 pf[4];                                          // (bit pattern: f16 values when F16; probabilities are <= 2^RESCALE_TAU)
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f) {
+        if constexpr (F16) {
+          f16x8 hp;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
+          for (int j = 0; j < 8; ++j) hp[j] = (_Float16)sc[8 * f + j];
+          pf[f] = __builtin_bit_cast(bf16x8, hp);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
+        }
+      }
       if (do_pv) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int t = 0; t < C::DVT; ++t)                 // alternate the d-blocks of O^T for the same reason
-            o_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vfr[t][f]), pf[f], o_acc[t], 0, 0, 0);
+            o_acc[t] = mfma_32x32x16<F16>(*reinterpret_cast<bf16x8*>(&vfr[t][f]), pf[f], o_acc[t]);
       }
       if (has_next) {                                        // the other buffer was last read one iteration ago
         bf16_t* nK = sbuf + (cur ^ 1) * BUF;
@@ -335,8 +362,8 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
         if (dv < DH) {
           uint2 o;
           const f32x16& of = MULTI ? o_tot[t] : o_acc[t];
-          o.x = pack_bf2(of[4 * g4 + 0] * a.out_scale, of[4 * g4 + 1] * a.out_scale);
-          o.y = pack_bf2(of[4 * g4 + 2] * a.out_scale, of[4 * g4 + 3] * a.out_scale);
+          o.x = pack_half2<F16>(of[4 * g4 + 0] * a.out_scale, of[4 * g4 + 1] * a.out_scale);
+          o.y = pack_half2<F16>(of[4 * g4 + 2] * a.out_scale, of[4 * g4 + 3] * a.out_scale);
           *reinterpret_cast<uint2*>(op + dv) = o;
         }
       }
@@ -349,9 +376,9 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   const size_t lds = (size_t)2 * (TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
   const bool generic = a.bias != nullptr || a.resoftmax != 0 || a.causal != 0;
   const bool multi = !a.sum_scores && a.n_terms > 1;
-  auto kern = generic ? (multi ? attn_kernel<DH, TS, true, true> : attn_kernel<DH, TS, true, false>)
-                      : (multi ? attn_kernel<DH, TS, false, true> : attn_kernel<DH, TS, false, false>);
-  if (lds > 64 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern = generic ? (multi ? attn_kernel<DH, TS, true, true, AF16> : attn_kernel<DH, TS, true, false, AF16>)
+                      : (multi ? attn_kernel<DH, TS, false, true, AF16> : attn_kernel<DH, TS, false, false, AF16>);
+  if (lds > 64 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t nqb = cdiv(a.N, QB);
   const int64_t nblk = (generic && a.bias) ? cdiv((int64_t)a.B * nqb, 8) * 8 * a.H : cdiv((int64_t)a.H * a.B, 8) * 8 * nqb;
   SG_REQUIRE(nblk < (1ll << 31), "attention: grid too large");
@@ -366,7 +393,12 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   return SG_OK;
 }
 
+#if SG_ATTN_F16
+int attention_f16_impl(const AttnArgs& a, hipStream_t s) {
+#else
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
+  if (a.f16) return attention_f16_impl(a, s);
+#endif
   SG_REQUIRE(a.n_terms >= 1 && a.n_terms <= 3, "attention: n_terms=%d", a.n_terms);
   SG_REQUIRE(a.B > 0 && a.N > 0 && a.H > 0, "attention: empty problem");
   SG_REQUIRE(a.B < 65536 && a.H < 65536, "attention: grid too large");
@@ -387,6 +419,7 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
 #undef SG_ATTN_CASE
 }
 
+#if !SG_ATTN_F16
 // ---- head-averaged statistics for outlier detection ------------------------------------------------------
 // One wave per token j: for every head, s_cls = scale * q[0].k[j], s_diag = scale * q[j].k[j];
 // probabilities are recovered from the per-row log-sum-exp the attention kernel wrote.
@@ -424,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(const T* __restrict__ q
 // Fast form for bf16 and head_dim 32 / 64 / 128: a lane owns 8 consecutive channels (one 16-byte load) of q[0], q[j], k[j]; the LPH = dh/8
 // lanes of a head reduce with log2(LPH) shuffles, one pass over the row handles 64/LPH heads at once (the generic kernel above does
 // two 6-step wave reductions per head).
-template <int LPH>
+template <int LPH, bool F16>
 __global__ __launch_bounds__(256) void attn_stats_fast_kernel(const bf16_t* __restrict__ qkv, int64_t sb, int64_t st, const float* __restrict__ lse,
                                                               int N, int H, float scale, float* __restrict__ attn_cls, float* __restrict__ attn_diag) {
   const int lane = threadIdx.x & 63;
@@ -445,9 +478,11 @@ __global__ __launch_bounds__(256) void attn_stats_fast_kernel(const bf16_t* __re
       const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w}, kw[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float k0 = __uint_as_float(kw[e] << 16), k1 = __uint_as_float(kw[e] & 0xffff0000u);
-        dc += __uint_as_float(aw[e] << 16) * k0 + __uint_as_float(aw[e] & 0xffff0000u) * k1;
-        dd += __uint_as_float(bw[e] << 16) * k0 + __uint_as_float(bw[e] & 0xffff0000u) * k1;
+        auto lo = [](uint32_t w) { if constexpr (F16) { f16_t h{(uint16_t)(w & 0xffffu)}; return h2f(h); } else return __uint_as_float(w << 16); };
+        auto hi = [](uint32_t w) { if constexpr (F16) { f16_t h{(uint16_t)(w >> 16)}; return h2f(h); } else return __uint_as_float(w & 0xffff0000u); };
+        const float k0 = lo(kw[e]), k1 = hi(kw[e]);
+        dc += lo(aw[e]) * k0 + hi(aw[e]) * k1;
+        dd += lo(bw[e]) * k0 + hi(bw[e]) * k1;
       }
     }
 #pragma unroll
@@ -470,17 +505,23 @@ int attention_stats(const void* qkv, int is_bf16, int64_t sb, int64_t st, const 
                     float scale, float* attn_cls, float* attn_diag, hipStream_t s) {
   dim3 grid((unsigned)cdiv(N, 4), (unsigned)B);
   const bool aligned = (sb % 8 == 0) && (st % 8 == 0) && ((((uintptr_t)qkv) & 15) == 0);
+#define SG_STATS_FAST(LPH, F)                                                                                                      \
+  hipLaunchKernelGGL((attn_stats_fast_kernel<LPH, F>), grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag)
   if (is_bf16 && aligned && (dh == 32 || dh == 64 || dh == 128)) {
-    if (dh == 32) hipLaunchKernelGGL(attn_stats_fast_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag);
-    else if (dh == 64) hipLaunchKernelGGL(attn_stats_fast_kernel<8>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag);
-    else hipLaunchKernelGGL(attn_stats_fast_kernel<16>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag);
+    const bool h = is_bf16 == HK_F16;
+    if (dh == 32) { if (h) SG_STATS_FAST(4, true); else SG_STATS_FAST(4, false); }
+    else if (dh == 64) { if (h) SG_STATS_FAST(8, true); else SG_STATS_FAST(8, false); }
+    else { if (h) SG_STATS_FAST(16, true); else SG_STATS_FAST(16, false); }
     SG_LAUNCH_CHECK();
     return SG_OK;
   }
-  if (is_bf16) hipLaunchKernelGGL(attn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
+#undef SG_STATS_FAST
+  if (is_bf16 == HK_F16) hipLaunchKernelGGL(attn_stats_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
+  else if (is_bf16) hipLaunchKernelGGL(attn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
   else hipLaunchKernelGGL(attn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }
+#endif  // !SG_ATTN_F16
 
 }  // namespace sg

@@ -96,7 +96,7 @@ struct sg_context {
   sg_vit_desc d;
   int device;
   int Kpatch, Kpad;
-  bool bf16;
+  int hk;                                              // HalfKind of the GEMM / attention operands: 0 = f32 (parity mode), 1 = bf16, 2 = f16
   bool fp8;                                            // SG_PREC_FP8: bf16 machinery + fp8 linears in the ordinary blocks
   size_t esz;                                          // bytes per element of the compute dtype
   void* arena; size_t arena_bytes;
@@ -146,14 +146,14 @@ struct AttnSpec {
   bool want_lse;
 };
 
-static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int dh, const AttnBuffers& buf, hipStream_t s) {
+static int attn_generic(int bf16, const AttnSpec& sp, int B, int N, int H, int dh, const AttnBuffers& buf, hipStream_t s) {
   if (bf16) {
     AttnArgs a{};
     for (int t = 0; t < sp.n_terms; ++t) { a.q[t] = (const bf16_t*)sp.q[t]; a.k[t] = (const bf16_t*)sp.k[t]; }
     a.v = (const bf16_t*)sp.v; a.sb = sp.sb; a.st = sp.st; a.v_sb = sp.v_sb; a.v_st = sp.v_st;
     a.n_terms = sp.n_terms; a.sum_scores = sp.sum_scores; a.causal = sp.causal;
     a.B = B; a.N = N; a.H = H; a.dh = dh; a.scale = sp.scale; a.scale_per_image = sp.scale_per_image;
-    a.out_scale = sp.out_scale; a.ctx_sb = sp.ctx_sb; a.ctx_st = sp.ctx_st;
+    a.out_scale = sp.out_scale; a.ctx_sb = sp.ctx_sb; a.ctx_st = sp.ctx_st; a.f16 = bf16 == HK_F16;
     if (sp.resoftmax) {
       AttnArgs p = a; p.ctx = nullptr; p.bias = nullptr; p.lse_out = buf.lse1; p.resoftmax = 0;
       SG_TRY(attention_bf16(p, s));
@@ -193,7 +193,7 @@ static int attn_generic(bool bf16, const AttnSpec& sp, int B, int N, int H, int 
 }
 
 // Attention over packed qkv [B,N,3D] (compute dtype) -> ctx [B,N,D] (compute dtype).
-static int run_attention(bool bf16, const void* qkv, int B, int N, int D, int H, int model_type, const float* sim, float sim_w,
+static int run_attention(int bf16, const void* qkv, int B, int N, int D, int H, int model_type, const float* sim, float sim_w,
                          const float* scale_per_image, void* ctx, bool want_lse, const AttnBuffers& buf, hipStream_t s, bool causal = false) {
   const int dh = D / H;
   Variant v;
@@ -223,12 +223,13 @@ static int run_attention(bool bf16, const void* qkv, int B, int N, int D, int H,
 }
 
 // y = act(A . W^T + bias) (+ residual) in the context's compute dtype; out_f32 forces an f32 C.
-static int linear(bool bf16, const void* A, int64_t lda, const void* W, const float* bias, const float* residual, void* C,
+static int linear(int bf16, const void* A, int64_t lda, const void* W, const float* bias, const float* residual, void* C,
                   int64_t ldc, bool c_f32, int M, int N, int K, int act, hipStream_t s) {
   if (bf16) {
     GemmBf16Args g{};
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
     g.C = C; g.ldc = ldc; g.c_is_bf16 = c_f32 ? 0 : 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f;
+    g.f16 = bf16 == HK_F16;
     return gemm_bf16(g, s);
   }
   GemmF32Args g{};
@@ -251,18 +252,18 @@ __global__ void zero_diag_kernel(float* sim, int n, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) sim[(i / n) * (int64_t)n * n + (i % n) * (int64_t)(n + 1)] = 0.f;
 }
-__global__ void unpack_bf16_kernel(const bf16_t* src, float* dst, int64_t n) {
+__global__ void unpack_bf16_kernel(const bf16_t* src, float* dst, int64_t n, int f16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = bf2f(src[i]);
+  if (i < n) dst[i] = f16 ? h2f(f16_t{src[i]}) : bf2f(src[i]);
 }
 
 // similarity map from L2-normalised patch rows xhat [B,n,D] (compute dtype) -> sim [B,n,n] f32
-static int similarity_from_xhat(bool bf16, const void* xhat, int B, int n, int D, float temperature, int add_self, float* sim, hipStream_t s) {
+static int similarity_from_xhat(int bf16, const void* xhat, int B, int n, int D, float temperature, int add_self, float* sim, hipStream_t s) {
   if (bf16) {
     GemmBf16Args g{};
     g.A = (const bf16_t*)xhat; g.lda = D; g.strideA = (int64_t)n * D; g.W = (const bf16_t*)xhat; g.ldw = D; g.strideW = (int64_t)n * D;
     g.C = sim; g.ldc = n; g.strideC = (int64_t)n * n; g.c_is_bf16 = 0; g.M = n; g.N = n; g.K = D; g.batch = B; g.act = 0;
-    g.alpha = 1.0f / temperature;
+    g.alpha = 1.0f / temperature; g.f16 = bf16 == HK_F16;
     SG_TRY(gemm_bf16(g, s));
   } else {
     GemmF32Args g{};
@@ -324,11 +325,11 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   const int kmax = k_out > k_sa ? k_out : k_sa;
   p.refine_scratch = b.take(refine_scratch_bytes(B, d.width, kmax > 0 ? kmax : 1));
   p.scores = p.probs = nullptr;
-  if (!c->bf16) { p.scores = b.get<float>((size_t)B * d.heads * N * N); p.probs = b.get<float>((size_t)B * d.heads * N * N); }
+  if (!c->hk) { p.scores = b.get<float>((size_t)B * d.heads * N * N); p.probs = b.get<float>((size_t)B * d.heads * N * N); }
   p.attn_avg = p.sa_tmp = p.sa_qk32 = p.sa_scores = p.sa_probs = nullptr;
   if (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1) {
     p.attn_avg = b.get<float>((size_t)B * N * N); p.sa_tmp = b.get<float>(R * d.width);
-    if (c->bf16) {                                        // one image at a time: f32 copies of q|k, scores and probabilities of all heads
+    if (c->hk) {                                        // one image at a time: f32 copies of q|k, scores and probabilities of all heads
       p.sa_qk32 = b.get<float>((size_t)N * 2 * d.width); p.sa_scores = b.get<float>((size_t)d.heads * N * N); p.sa_probs = b.get<float>((size_t)d.heads * N * N);
     }
   }
@@ -378,7 +379,7 @@ extern "C" int sg_profile_enable(int capacity) {
 extern "C" int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                                 int act, int c_is_bf16, sg_stream st) {
   SG_REQUIRE(A && W && C, "sg_gemm_bf16_raw: null pointer");
-  return linear(true, A, K, W, bias, residual, C, N, !c_is_bf16, M, N, K, act, as_stream(st));
+  return linear(HK_BF16, A, K, W, bias, residual, C, N, !c_is_bf16, M, N, K, act, as_stream(st));
 }
 // fp8 (OCP e4m3) GEMM on caller-quantised operands: A8 [M,K] with per-row scales sa [M], W8 [N,K] with per-row scales sw [N], K % 128 == 0.
 extern "C" int sg_gemm_fp8_raw(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, const float* residual,
@@ -417,7 +418,7 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
   const sg_vit_desc& d = *desc;
   SG_REQUIRE(d.width > 0 && d.layers >= 2 && d.heads > 0 && d.width % d.heads == 0 && d.patch > 0 && d.embed_dim > 0 && d.grid0 > 0 &&
              d.mlp_width > 0, "sg_create: bad descriptor");
-  SG_REQUIRE(d.precision == SG_PREC_F32 || d.precision == SG_PREC_BF16 || d.precision == SG_PREC_FP8, "sg_create: bad precision %d", d.precision);
+  SG_REQUIRE(d.precision == SG_PREC_F32 || d.precision == SG_PREC_BF16 || d.precision == SG_PREC_FP8 || d.precision == SG_PREC_F16, "sg_create: bad precision %d", d.precision);
   SG_REQUIRE(d.width % 4 == 0 && d.embed_dim % 4 == 0, "sg_create: width / embed_dim must be multiples of 4");
   if (d.precision == SG_PREC_FP8)
     SG_REQUIRE(d.width % 128 == 0 && d.mlp_width % 128 == 0, "sg_create: fp8 mode needs width and mlp_width to be multiples of 128");
@@ -428,8 +429,9 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
   }
   DeviceGuard dg(device);
   sg_context* c = new sg_context();
-  c->d = d; c->device = device; c->bf16 = d.precision != SG_PREC_F32; c->fp8 = d.precision == SG_PREC_FP8;
-  c->esz = c->bf16 ? 2 : 4;
+  c->d = d; c->device = device; c->fp8 = d.precision == SG_PREC_FP8;
+  c->hk = d.precision == SG_PREC_F32 ? HK_F32 : (d.precision == SG_PREC_F16 ? HK_F16 : HK_BF16);
+  c->esz = c->hk ? 2 : 4;
   c->Kpatch = 3 * d.patch * d.patch;
   c->Kpad = (int)align_up(c->Kpatch, 64);
   c->finalized = false;
@@ -479,7 +481,7 @@ extern "C" int sg_vit_set_tensor(sg_context* c, const char* name, const float* s
   hipStream_t s = as_stream(st);
   const sg_vit_desc& d = c->d;
   const int D = d.width, M = d.mlp_width, E = d.embed_dim;
-  const int to_bf16 = c->bf16 ? 1 : 0;
+  const int to_bf16 = c->hk;
   auto copyf = [&](float* dst, int64_t n) -> int {
     SG_REQUIRE(numel == n, "sg_vit_set_tensor(%s): expected %lld elements, got %lld", name, (long long)n, (long long)numel);
     SG_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -563,9 +565,9 @@ static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
     SG_TRY(quantize_rows_fp8(p.hbuf, 1, M, p.h8, M, p.sh8, R, M, s));
     return linear_fp8(p.h8, p.sh8, M, L.w_proj8, L.s_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s);
   }
-  SG_TRY(layernorm(x, D, L.ln2_g, L.ln2_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
-  SG_TRY(linear(c->bf16, p.xn, D, L.w_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
-  SG_TRY(linear(c->bf16, p.hbuf, M, L.w_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s));
+  SG_TRY(layernorm(x, D, L.ln2_g, L.ln2_b, p.xn, D, c->hk, R, D, 1e-5f, s));
+  SG_TRY(linear(c->hk, p.xn, D, L.w_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
+  SG_TRY(linear(c->hk, p.hbuf, M, L.w_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s));
   return SG_OK;
 }
 
@@ -581,25 +583,26 @@ static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
     SG_TRY(layernorm_fp8(x, D, L.ln1_g, L.ln1_b, p.x8, D, p.sx8, R, D, 1e-5f, s));
     SG_TRY(linear_fp8(p.x8, p.sx8, D, L.w_qkv8, L.s_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
   } else {
-    SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
-    SG_TRY(linear(c->bf16, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+    SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->hk, R, D, 1e-5f, s));
+    SG_TRY(linear(c->hk, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
   }
-  SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s, causal));
+  SG_TRY(run_attention(c->hk, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s, causal));
   if (stats)
-    SG_TRY(attention_stats(p.qkv, c->bf16, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), p.attn_cls,
+    SG_TRY(attention_stats(p.qkv, c->hk, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), p.attn_cls,
                            p.attn_diag, s));
   if (want_avg) SG_TRY(averaged_attention(c, p, B, N, s));
-  SG_TRY(linear(c->bf16, p.ctx, D, L.w_out, L.b_out, x, x, D, true, (int)R, D, D, ACT_NONE, s));
+  SG_TRY(linear(c->hk, p.ctx, D, L.w_out, L.b_out, x, x, D, true, (int)R, D, D, ACT_NONE, s));
   return mlp_block(c, L, x, p, R, s);
 }
 
 static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan& p, int B, int N, hipStream_t s);
 
-__global__ void unpack_qk_kernel(const bf16_t* __restrict__ qkv, int N, int D, float* __restrict__ out) {
+__global__ void unpack_qk_kernel(const bf16_t* __restrict__ qkv, int N, int D, float* __restrict__ out, int f16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)N * 2 * D) return;
   const int t = (int)(i / (2 * D)), c = (int)(i % (2 * D));
-  out[i] = bf2f(qkv[(int64_t)t * 3 * D + c]);
+  const bf16_t v = qkv[(int64_t)t * 3 * D + c];
+  out[i] = f16 ? h2f(f16_t{v}) : bf2f(v);
 }
 // head-averaged attention matrix [B,N,N] of the block whose packed qkv is in p.qkv (the tensor the reference gets from
 // nn.MultiheadAttention(need_weights=True), transformer.py:609-610).  Only the optional mode='attention' enhancer needs it.
@@ -607,11 +610,11 @@ static int averaged_attention(sg_context* c, const Plan& p, int B, int N, hipStr
   const sg_vit_desc& d = c->d;
   const int D = d.width, H = d.heads, dh = D / H;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (!c->bf16) return head_mean(p.probs, B, H, N, p.attn_avg, s);        // parity mode: the probabilities are materialised already
+  if (!c->hk) return head_mean(p.probs, B, H, N, p.attn_avg, s);        // parity mode: the probabilities are materialised already
   const int64_t NN = (int64_t)N * N;
   for (int b = 0; b < B; ++b) {
     const bf16_t* qkv = (const bf16_t*)p.qkv + (int64_t)b * N * 3 * D;
-    hipLaunchKernelGGL(unpack_qk_kernel, dim3((unsigned)cdiv((int64_t)N * 2 * D, 256)), dim3(256), 0, s, qkv, N, D, p.sa_qk32);
+    hipLaunchKernelGGL(unpack_qk_kernel, dim3((unsigned)cdiv((int64_t)N * 2 * D, 256)), dim3(256), 0, s, qkv, N, D, p.sa_qk32, c->hk == HK_F16 ? 1 : 0);
     SG_LAUNCH_CHECK();
     GemmF32Args g{};
     g.A = p.sa_qk32; g.lda = 2 * D; g.sAi = dh; g.B = p.sa_qk32 + D; g.sbk = 1; g.sbn = 2 * D; g.sBi = dh;
@@ -646,8 +649,8 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
 
   // ---- prologue: patch embed, class token, positional embedding, ln_pre (transformer.py:559-576) ----
   const bool gem = o->model_type == SG_GEM;
-  SG_TRY(patchify(*tiles, d.patch, p.patchA, c->Kpad, c->bf16, s));
-  SG_TRY(linear(c->bf16, p.patchA, c->Kpad, c->w_patch, nullptr, nullptr, p.patchOut, D, true, B * n, D, c->Kpad, ACT_NONE, s));
+  SG_TRY(patchify(*tiles, d.patch, p.patchA, c->Kpad, c->hk, s));
+  SG_TRY(linear(c->hk, p.patchA, c->Kpad, c->w_patch, nullptr, nullptr, p.patchOut, D, true, B * n, D, c->Kpad, ACT_NONE, s));
   const float* pos = c->pos;
   if (gh != d.grid0 || gw != d.grid0) { SG_TRY(posembed_resize(c->pos, d.grid0, D, gh, gw, gem ? 1 : 0, p.pos_r, s)); pos = p.pos_r; }
   SG_TRY(embed_assemble(p.patchOut, D, c->cls_emb, pos, c->lnpre_g, c->lnpre_b, p.x, B, N, D, 1e-5f, s));
@@ -657,28 +660,28 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     SG_REQUIRE(o->gem_depth >= 2 && first >= 0, "sg_vit_forward: gem_depth %d does not fit %d layers", o->gem_depth, L);
     for (int i = 0; i < first; ++i) SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, false, s));
     SG_TRY(gem_forward_tail(c, o, p, B, N, s));
-    SG_TRY(layernorm(p.x_gem, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+    SG_TRY(layernorm(p.x_gem, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->hk, R, D, 1e-5f, s));
   } else {
     const int mid = (L - 1) / 2;                                      // transformer.py:593
     const bool want_stats = o->outlier_enabled != 0;                  // transformer.py:609 (R6)
     for (int i = 0; i < L - 1; ++i) {
       if (i == mid && o->similarity_enabled)                          // normalised mid-layer patches (similarity_enhancement.py:49)
-        SG_TRY(l2norm_rows(p.x + D, 0, (int64_t)N * D, D, n, p.xhat, c->bf16, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));
+        SG_TRY(l2norm_rows(p.x + D, 0, (int64_t)N * D, D, n, p.xhat, c->hk, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));
       SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, want_stats && i == L - 2, s,
                        want_stats && i == L - 2 && o->selfattn_enabled && o->selfattn_mode == 1));
     }
     if (o->similarity_enabled)
-      SG_TRY(similarity_from_xhat(c->bf16, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s));
+      SG_TRY(similarity_from_xhat(c->hk, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s));
     // ---- last block: self-self attention on ln_1(x), no residual / MLP when ignore_residual (transformer.py:627-643) ----
     const LayerW& LL = c->layers[L - 1];
     AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1, p.omega, p.qnorm, p.knorm};
-    SG_TRY(layernorm(p.x, D, LL.ln1_g, LL.ln1_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
-    SG_TRY(linear(c->bf16, p.xn, D, LL.w_qkv, LL.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+    SG_TRY(layernorm(p.x, D, LL.ln1_g, LL.ln1_b, p.xn, D, c->hk, R, D, 1e-5f, s));
+    SG_TRY(linear(c->hk, p.xn, D, LL.w_qkv, LL.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
     const void* ctx = p.ctx; int64_t ctx_ld = D;
     if (o->model_type == SG_MASKCLIP) { ctx = (const char*)p.qkv + (size_t)2 * D * c->esz; ctx_ld = 3 * D; }   // identity attention: ctx = v
-    else SG_TRY(run_attention(c->bf16, p.qkv, B, N, D, H, o->model_type, (o->similarity_enabled && o->model_type < SG_NACLIP) ? p.sim : nullptr, o->similarity_weight,
+    else SG_TRY(run_attention(c->hk, p.qkv, B, N, D, H, o->model_type, (o->similarity_enabled && o->model_type < SG_NACLIP) ? p.sim : nullptr, o->similarity_weight,
                               nullptr, p.ctx, false, ab, s));
-    SG_TRY(linear(c->bf16, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
+    SG_TRY(linear(c->hk, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
     if (!o->ignore_residual) SG_TRY(mlp_block(c, LL, p.out_last, p, R, s));
     // ---- refinements on the last-block output (transformer.py:698-742) ----
     if (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1) {
@@ -693,10 +696,10 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
       SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 0, p.idx_out, s));
       SG_TRY(neighbour_refine(p.out_last, (int64_t)N * D, D, p.idx_out, B, gh, gw, D, k, 1, o->outlier_contamination_temp, p.refine_scratch, s));
     }
-    SG_TRY(layernorm(p.out_last, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->bf16, R, D, 1e-5f, s));
+    SG_TRY(layernorm(p.out_last, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->hk, R, D, 1e-5f, s));
   }
   // ---- epilogue: `@ proj` on every token (transformer.py:765-770) ----
-  SG_TRY(linear(c->bf16, p.xn, D, c->w_projT, nullptr, nullptr, p.y, E, true, (int)R, E, D, ACT_NONE, s));
+  SG_TRY(linear(c->hk, p.xn, D, c->w_projT, nullptr, nullptr, p.y, E, true, (int)R, E, D, ACT_NONE, s));
   if (out_cls && !gem)
     SG_HIP(hipMemcpy2DAsync(out_cls, (size_t)E * 4, p.y, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s));
   SG_HIP(hipMemcpy2DAsync(out_tokens, (size_t)n * E * 4, p.y + E, (size_t)N * E * 4, (size_t)n * E * 4, B, hipMemcpyDeviceToDevice, s));
@@ -710,7 +713,7 @@ static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan&
   const int64_t R = (int64_t)B * N;
   const float scale = 1.0f / sqrtf((float)dh);
   const int first = L - (o->gem_depth - 1);
-  const bool bf = c->bf16;
+  const int bf = c->hk;
   SG_HIP(hipMemcpyAsync(p.x_gem, p.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
   AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1, nullptr, nullptr, nullptr};
   for (int i = first; i < L; ++i) {
@@ -794,9 +797,9 @@ extern "C" int sg_text_create(sg_text** out, int device, int width, int layers, 
                               int quick_gelu, int precision) {
   SG_REQUIRE(out && width > 0 && layers > 0 && heads > 0 && width % heads == 0 && context_length > 0 && vocab_size > 0 && embed_dim > 0,
              "sg_text_create: bad arguments");
-  SG_REQUIRE(precision == SG_PREC_F32 || precision == SG_PREC_BF16, "sg_text_create: bad precision");
+  SG_REQUIRE(precision == SG_PREC_F32 || precision == SG_PREC_BF16 || precision == SG_PREC_F16, "sg_text_create: bad precision");
   SG_REQUIRE(width % 4 == 0 && embed_dim % 4 == 0, "sg_text_create: width / embed_dim must be multiples of 4");
-  if (precision == SG_PREC_BF16) {
+  if (precision != SG_PREC_F32) {
     const int dh = width / heads;
     SG_REQUIRE(width % 64 == 0 && (dh == 32 || dh == 64 || dh == 80 || dh == 128), "sg_text_create: bf16 mode needs width %% 64 == 0 and head_dim 32/64/80/128");
   }
@@ -804,7 +807,7 @@ extern "C" int sg_text_create(sg_text** out, int device, int width, int layers, 
   sg_text* t = new sg_text();
   sg_context& c = t->core;
   c.d = sg_vit_desc{width, layers, heads, 1, embed_dim, 1, 4 * width, quick_gelu, precision};
-  c.device = device; c.bf16 = precision == SG_PREC_BF16; c.esz = c.bf16 ? 2 : 4; c.Kpatch = c.Kpad = 0; c.finalized = false;
+  c.device = device; c.hk = precision == SG_PREC_F32 ? HK_F32 : (precision == SG_PREC_F16 ? HK_F16 : HK_BF16); c.esz = c.hk ? 2 : 4; c.Kpatch = c.Kpad = 0; c.finalized = false;
   t->context_length = context_length; t->vocab_size = vocab_size; t->embed_dim = embed_dim;
   auto lay = [&](Bump& bb) {
     const size_t e = c.esz; const int D = width, M = 4 * width;
@@ -840,7 +843,7 @@ extern "C" int sg_text_set_tensor(sg_text* t, const char* name, const float* src
   hipStream_t s = as_stream(st);
   sg_context& c = t->core;
   const int D = c.d.width, M = c.d.mlp_width, E = t->embed_dim;
-  const int to_bf16 = c.bf16 ? 1 : 0;
+  const int to_bf16 = c.hk;
   auto copyf = [&](float* dst, int64_t n) -> int {
     SG_REQUIRE(numel == n, "sg_text_set_tensor(%s): expected %lld elements, got %lld", name, (long long)n, (long long)numel);
     SG_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -897,7 +900,7 @@ static size_t text_plan(const sg_text* t, int S, void* ws, bool dry, Plan& p, fl
   p.lse = b.get<float>((size_t)S * c.d.heads * N); p.lse1 = b.get<float>((size_t)S * c.d.heads * N);
   p.attn_cls = p.attn_diag = nullptr; p.omega = p.qnorm = p.knorm = nullptr; p.attn_avg = nullptr;
   p.scores = p.probs = nullptr;
-  if (!c.bf16) { p.scores = b.get<float>((size_t)S * c.d.heads * N * N); p.probs = b.get<float>((size_t)S * c.d.heads * N * N); }
+  if (!c.hk) { p.scores = b.get<float>((size_t)S * c.d.heads * N * N); p.probs = b.get<float>((size_t)S * c.d.heads * N * N); }
   pooled = b.get<float>((size_t)S * D);
   p.idx_out = b.get<int32_t>(1);                            // out-of-vocabulary flag of text_embed_kernel
   return align_up(b.off, 256);
@@ -927,8 +930,8 @@ extern "C" int sg_text_encode(sg_text* t, const int32_t* tokens, int n_seq, floa
   for (int i = 0; i < c.d.layers; ++i) SG_TRY(std_block(&c, c.layers[i], x, p, S, N, false, s, false, /*causal=*/true));
   hipLaunchKernelGGL(text_pool_kernel, dim3(S), dim3(256), 0, s, tokens, x, N, D, pooled);
   SG_LAUNCH_CHECK();
-  SG_TRY(layernorm(pooled, D, t->lnf_g, t->lnf_b, p.xn, D, c.bf16, S, D, 1e-5f, s));
-  SG_TRY(linear(c.bf16, p.xn, D, t->w_projT, nullptr, nullptr, out, E, true, S, E, D, ACT_NONE, s));
+  SG_TRY(layernorm(pooled, D, t->lnf_g, t->lnf_b, p.xn, D, c.hk, S, D, 1e-5f, s));
+  SG_TRY(linear(c.hk, p.xn, D, t->w_projT, nullptr, nullptr, out, E, true, S, E, D, ACT_NONE, s));
   // init-time call: the one entry point that synchronises, so that an id outside the vocabulary is an error as in the reference
   // (nn.Embedding raises, open_clip/model.py:292) instead of a silently clamped row
   int32_t bad = 0;
@@ -948,21 +951,22 @@ extern "C" int sg_op_linear(const float* A, const float* W, const float* bias, c
                             int act, int precision, void* scratch, size_t scratch_bytes, sg_stream st) {
   SG_REQUIRE(A && W && C, "sg_op_linear: null pointer");
   hipStream_t s = as_stream(st);
-  if (precision == SG_PREC_F32) return linear(false, A, K, W, bias, residual, C, N, true, M, N, K, act, s);
+  if (precision == SG_PREC_F32) return linear(HK_F32, A, K, W, bias, residual, C, N, true, M, N, K, act, s);
+  const int hk = precision == SG_PREC_F16 ? HK_F16 : HK_BF16;
   const int Kp = (int)align_up(K, 64);
   const size_t need = align_up((size_t)M * Kp * 2, 256) + (size_t)N * Kp * 2;
   if (!scratch || scratch_bytes < need) return fail(SG_ERR_STATE, "sg_op_linear: scratch %zu < %zu", scratch_bytes, need);
   bf16_t* a16 = (bf16_t*)scratch;
   bf16_t* w16 = (bf16_t*)((char*)scratch + align_up((size_t)M * Kp * 2, 256));
-  SG_TRY(pack_rows(A, M, K, K, a16, Kp, 1, s));
-  SG_TRY(pack_rows(W, N, K, K, w16, Kp, 1, s));
-  return linear(true, a16, Kp, w16, bias, residual, C, N, true, M, N, Kp, act, s);
+  SG_TRY(pack_rows(A, M, K, K, a16, Kp, hk, s));
+  SG_TRY(pack_rows(W, N, K, K, w16, Kp, hk, s));
+  return linear(hk, a16, Kp, w16, bias, residual, C, N, true, M, N, Kp, act, s);
 }
 
 extern "C" size_t sg_op_attention_scratch_bytes(int B, int N, int D, int H, int precision) {
   const size_t R = (size_t)B * N;
   size_t b = 4 * 256 + 2 * align_up((size_t)B * H * N * 4, 256) + align_up((size_t)(N - 1) * (N - 1) * 4, 256) + 2 * align_up((size_t)B * H * N * 4, 256);
-  if (precision == SG_PREC_BF16) b += align_up(R * 3 * D * 2, 256) + align_up(R * D * 2, 256);
+  if (precision != SG_PREC_F32) b += align_up(R * 3 * D * 2, 256) + align_up(R * D * 2, 256);
   else b += 2 * align_up((size_t)B * H * N * N * 4, 256);
   return b + 4096;
 }
@@ -973,7 +977,7 @@ extern "C" int sg_op_attention(const float* qkv, int B, int N, int D, int H, int
   SG_REQUIRE(D % H == 0, "sg_op_attention: D %% H != 0");
   hipStream_t s = as_stream(st);
   const int64_t R = (int64_t)B * N;
-  const bool bf = precision == SG_PREC_BF16;
+  const int bf = precision == SG_PREC_F32 ? HK_F32 : (precision == SG_PREC_F16 ? HK_F16 : HK_BF16);
   Bump b(scratch, scratch_bytes, false);
   AttnBuffers ab{};
   ab.lse = b.get<float>((size_t)B * H * N); ab.lse1 = b.get<float>((size_t)B * H * N);
@@ -982,13 +986,13 @@ extern "C" int sg_op_attention(const float* qkv, int B, int N, int D, int H, int
   if (bf) { qkv_c = b.take((size_t)R * 3 * D * 2); ctx_c = b.take((size_t)R * D * 2); }
   else { ab.scores = b.get<float>((size_t)B * H * N * N); ab.probs = b.get<float>((size_t)B * H * N * N); }
   if (b.off > scratch_bytes) return fail(SG_ERR_STATE, "sg_op_attention: scratch %zu < %zu", scratch_bytes, b.off);
-  if (bf) SG_TRY(pack_rows(qkv, R, 3 * D, 3 * D, qkv_c, 3 * D, 1, s));
+  if (bf) SG_TRY(pack_rows(qkv, R, 3 * D, 3 * D, qkv_c, 3 * D, bf, s));
   const bool stats = attn_cls && attn_diag;
   if (variant == SG_MASKCLIP) return fail(SG_ERR_INVALID, "sg_op_attention: MaskCLIP is the identity (ctx = v)");
   SG_TRY(run_attention(bf, qkv_c, B, N, D, H, variant, sim, sim_weight, nullptr, ctx_c, stats, ab, s));
   if (stats) SG_TRY(attention_stats(qkv_c, bf, (int64_t)N * 3 * D, 3 * D, ab.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), attn_cls, attn_diag, s));
   if (bf) {
-    hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, (const bf16_t*)ctx_c, ctx, R * D);
+    hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, (const bf16_t*)ctx_c, ctx, R * D, bf == HK_F16 ? 1 : 0);
     SG_LAUNCH_CHECK();
   }
   return SG_OK;
@@ -998,7 +1002,7 @@ extern "C" int sg_similarity_map(const float* patches, int64_t batch_stride, int
                                  int precision, float* sim, void* scratch, size_t scratch_bytes, sg_stream st) {
   SG_REQUIRE(patches && sim && scratch, "sg_similarity_map: null pointer");
   hipStream_t s = as_stream(st);
-  const bool bf = precision == SG_PREC_BF16;
+  const int bf = precision == SG_PREC_F32 ? HK_F32 : (precision == SG_PREC_F16 ? HK_F16 : HK_BF16);
   const size_t need = (size_t)B * n * D * (bf ? 2 : 4);
   if (scratch_bytes < need) return fail(SG_ERR_STATE, "sg_similarity_map: scratch %zu < %zu", scratch_bytes, need);
   if (bf) SG_REQUIRE(D % 64 == 0, "sg_similarity_map: bf16 mode needs D %% 64 == 0");

@@ -72,12 +72,40 @@ __device__ __forceinline__ bf16_t f2bf(float f) {                    // round-to
 }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+// ---- f16 (SG_PREC_F16): a distinct storage type so the row kernels can be instantiated for it ----------------
+// The reference's GPU arithmetic is fp16 + fp32 LayerNorm (segmentor.py:467, open_clip/model.py:142); gfx950 runs the f16 MFMA
+// forms at the bf16 rate.  Stores SATURATE at +-65504 instead of producing inf (QKV / fc outputs of a trained tower can be large).
+struct f16_t { uint16_t bits; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+constexpr float F16_MAX = 65504.0f;
+__device__ __forceinline__ float h2f(f16_t v) { _Float16 h; __builtin_memcpy(&h, &v.bits, 2); return (float)h; }
+__device__ __forceinline__ f16_t f2h(float f) {
+  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -F16_MAX, F16_MAX);   // round-to-nearest-even; NaN stays NaN
+  f16_t o; __builtin_memcpy(&o.bits, &h, 2); return o;
+}
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) { return (uint32_t)f2h(lo).bits | ((uint32_t)f2h(hi).bits << 16); }
+// half-precision kind of a buffer / kernel: 0 = f32, 1 = bf16, 2 = f16 (every `int ..._bf16` flag of the internal ops takes these values)
+enum HalfKind { HK_F32 = 0, HK_BF16 = 1, HK_F16 = 2 };
+template <bool F16> __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) { return F16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); }
+__device__ __forceinline__ uint32_t pack_half2(int kind, float lo, float hi) { return kind == HK_F16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); }
+// MFMA on 2-byte operands held as bf16x8 bit patterns: the f16 forms take the same cycles as the bf16 forms (MI355X_MICROARCH.md)
+template <bool F16> __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return h2f(v); }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return f2h(v); }
 
 // ---- wave-level reductions (64 lanes) ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -112,7 +140,8 @@ struct GemmBf16Args {
   const bf16_t* W; int64_t ldw; int64_t strideW;
   const float* bias;                                  // [N] or null
   const float* residual; int64_t ldr;                 // f32 [M,N] or null (batch stride = strideC)
-  void* C; int64_t ldc; int64_t strideC; int c_is_bf16;
+  void* C; int64_t ldc; int64_t strideC; int c_is_bf16;   // C: 0 = f32, 1 = the operands' 2-byte type (bf16, or f16 when `f16` is set)
+  int f16;                                            // operands (and a 2-byte C) are IEEE f16 instead of bf16: SG_PREC_F16
   int M, N, K, batch, act;
   float alpha;                                        // applied to the accumulator before bias
   // fp8 mode (fp8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K % 128 == 0); lda / ldw / K stay in ELEMENTS (= bytes);

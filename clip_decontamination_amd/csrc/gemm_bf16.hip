@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
 // tile goes through a private LDS patch (row stride TN+4 floats: conflict-free 16-byte writes) and comes back row-contiguous, so a
 // store instruction writes WHOLE 128-byte lines (8 rows x 128 B bf16, 4 rows x 256 B f32); bias / activation are applied before
 // the patch, the f32 residual is added on the way out with equally coalesced loads.
-template <int MI, int NI>
+template <int MI, int NI, bool F16 = false>
 __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
                                                int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
         if (r < 16 && m < a.M && n < a.N) {
           const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
           const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
-          uint4 o; o.x = pack_bf2(x0.x, x0.y); o.y = pack_bf2(x0.z, x0.w); o.z = pack_bf2(x1.x, x1.y); o.w = pack_bf2(x1.z, x1.w);
+          uint4 o; o.x = pack_half2<F16>(x0.x, x0.y); o.y = pack_half2<F16>(x0.z, x0.w); o.z = pack_half2<F16>(x1.x, x1.y); o.w = pack_half2<F16>(x1.z, x1.w);
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
         }
       }
@@ -233,7 +233,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 64 'bf16' = 128 fp8 per row), so staging, swizzle and fragment reads are unchanged; the two 16-byte fragment reads of a K tile
 // are concatenated into the 32-byte operand of ONE v_mfma_f32_16x16x128_f8f6f4 (both operands use the same K permutation).
 // The legacy v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate on gfx950 (tools/mfma_rate.hip: 2.1 vs 4.8 PFLOP/s), so it is not used.
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MI = TM / 16, NI = TN / 16;
   constexpr int RPS = BKT == 64 ? 8 : 16;                // rows per 1 KiB slab (row = BKT * 2 bytes)
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          if (ABLATE != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+          if (ABLATE != 2) acc[i][j] = mfma_16x16x32<F16>(fw[j], fa[i], acc[i][j]);
           else { asm volatile("" ::"v"(fw[j]), "v"(fa[i])); }
     }
   }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
   }
   if (vec) {                                               // N % 8 == 0, aligned: coalesced path through an LDS patch
     __syncthreads();                                       // every wave is done reading the staging buffers
-    epilogue_store<MI, NI>(acc, a, act, c_bf16, z, m0 + wave_m * TM, n0 + wave_n * TN, reinterpret_cast<float*>(lds) + wave * 16 * (TN + 4), lane);
+    epilogue_store<MI, NI, F16>(acc, a, act, c_bf16, z, m0 + wave_m * TM, n0 + wave_n * TN, reinterpret_cast<float*>(lds) + wave * 16 * (TN + 4), lane);
     return;
   }
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
         }
         if (c_bf16) {
           bf16_t* C = reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
-          uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+          uint2 o; o.x = pack_half2<F16>(v[0], v[1]); o.y = pack_half2<F16>(v[2], v[3]);
           *reinterpret_cast<uint2*>(C) = o;
         } else {
           float* C = reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
           if (act == ACT_QUICK_GELU) x = quick_gelu(x);
           else if (act == ACT_GELU) x = erf_gelu(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
-          if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = f2bf(x);
+          if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
           else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
         }
       }
@@ -421,6 +421,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
 //   * RAW: every wave drains its own loads (vmcnt(0)) at the end of MFMA(t,3) (slot 8t+7 / 8t+8) before the barrier; the first
 //     readers of another group's rows come >= 1 slot after that barrier (group 0 reads group-1-loaded W rows in READ(t+1,1),
 //     slot 8t+10; group 1 reads group-0-loaded W rows in READ(t+1,0), slot 8t+9).
+template <bool F16>
 __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int PBM = 256, PBN = 256;
   constexpr int BUF_BYTES = (PBM + PBN) * BK * 2;          // 64 KiB
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
           acc[4 * (MH) + i][2 * (NH) + j] =                                                              \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][kk], fa[i][kk], acc[4 * (MH) + i][2 * (NH) + j], 0, 0, 0); \
+              mfma_16x16x32<F16>(fw[j][kk], fa[i][kk], acc[4 * (MH) + i][2 * (NH) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                       \
   } while (0)
 #define SG_PP_SYNC()                                 \
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
 
   if (vec) {
     __syncthreads();
-    epilogue_store<8, 4>(acc, a, act, c_bf16, z, m0 + 128 * g, n0 + 64 * wi, reinterpret_cast<float*>(lds) + wave * 16 * 68, lane);
+    epilogue_store<8, 4, F16>(acc, a, act, c_bf16, z, m0 + 128 * g, n0 + 64 * wi, reinterpret_cast<float*>(lds) + wave * 16 * 68, lane);
     return;
   }
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
         }
         if (c_bf16) {
           bf16_t* C = reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
-          uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+          uint2 o; o.x = pack_half2<F16>(v[0], v[1]); o.y = pack_half2<F16>(v[2], v[3]);
           *reinterpret_cast<uint2*>(C) = o;
         } else {
           float* C = reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
           if (act == ACT_QUICK_GELU) x = quick_gelu(x);
           else if (act == ACT_GELU) x = erf_gelu(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
-          if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = f2bf(x);
+          if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
           else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
         }
       }
@@ -593,10 +594,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
 
 static int launch_pingpong(const GemmBf16Args& a, int vec, hipStream_t s) {
   const size_t lds = 2 * (256 + 256) * BK * 2;
-  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_pingpong), lds));
+  auto kern = a.f16 ? gemm_bf16_pingpong<true> : gemm_bf16_pingpong<false>;
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
-  hipLaunchKernelGGL(gemm_bf16_pingpong, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, vec);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16, vec);
   return SG_OK;
 }
 
@@ -761,7 +763,7 @@ static int launch_pp32(const GemmBf16Args& a, hipStream_t s) {
 //        A(s+2), W(s+2), A(s+3) = 6), group 1 after READ(s) (tiles s+2, s+3 = 8); both before the barrier closing slot 2s+1.
 //   tile end: group 0 takes one extra barrier (both groups are then past every read of the tile's last K tile), every wave runs the
 //        coalescing epilogue through a private patch inside the just-consumed ring slot, one barrier, group 1 re-staggers.
-template <int MI, int NI>
+template <int MI, int NI, bool F16>
 __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
                                                 int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
@@ -822,7 +824,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
         if (r < 8 && m < a.M && n < a.N) {
           const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
           const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
-          uint4 o; o.x = pack_bf2(x0.x, x0.y); o.y = pack_bf2(x0.z, x0.w); o.z = pack_bf2(x1.x, x1.y); o.w = pack_bf2(x1.z, x1.w);
+          uint4 o; o.x = pack_half2<F16>(x0.x, x0.y); o.y = pack_half2<F16>(x0.z, x0.w); o.z = pack_half2<F16>(x1.x, x1.y); o.w = pack_half2<F16>(x1.z, x1.w);
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
         }
       } else {
@@ -847,6 +849,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act, int c_bf16) {
   constexpr int PBM = 256, PBN = 256, KT32 = 32;
   constexpr int TILE_B = (PBM + PBN) * KT32 * 2;             // 32 KiB per ring slot
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[jj], fa[i], acc[i][jj], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma_16x16x32<F16>(fw[jj], fa[i], acc[i][jj]);
       __builtin_amdgcn_s_setprio(0);
       if (g == 0) wait_tile(s + 1);
       SG_PS_SYNC();
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
     if (g == 0) SG_PS_SYNC();                               // align: every read of this tile's last K tile has retired
     {
       float* patch = reinterpret_cast<float*>(lds + ((s - 1) & 3) * TILE_B) + wave * 576;   // 8 rows x 68 floats (+pad) per wave
-      epilogue_store8<8, 4>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
+      epilogue_store8<8, 4, F16>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);
@@ -974,21 +977,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 
 static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
-  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_persist), lds));
+  auto kern = a.f16 ? gemm_bf16_persist<true> : gemm_bf16_persist<false>;
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int n_cu = device_cu_count();
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
-  hipLaunchKernelGGL(gemm_bf16_persist, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
+  hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
   return SG_OK;
 }
 
 static thread_local int g_gemm_config = -1;                // -1 = pick per shape (tuning override, per calling thread)
 void set_gemm_config(int c) { g_gemm_config = c; }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false>
 static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
-  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8>;
+  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8, F16>;
   const size_t lds = (size_t)STAGES * (BM_ + BN_) * BKT * 2;
   if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
@@ -1038,7 +1042,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   (void)csz;
   SG_REQUIRE(a.act >= 0 && a.act <= 2, "gemm_bf16: bad act %d", a.act);
   int cfg = g_gemm_config;
-  if (cfg < 0) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups)
+  if (cfg < 0 || a.f16) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
   if (cfg > 0) {
     const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? PROF_GEMM_PERSIST : PROF_GEMM_BF16;
     prof_begin(pcat, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
@@ -1047,7 +1051,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
       case 1: rc = launch_ring<128, 128, 2, 2, 3>(a, vec, s); break;
       case 2: rc = launch_ring<256, 128, 4, 2, 3>(a, vec, s); break;
       case 3: rc = launch_ring<256, 256, 2, 4, 2>(a, vec, s); break;
-      case 4: rc = launch_ring<128, 128, 2, 2, 2>(a, vec, s); break;
+      case 4: rc = a.f16 ? launch_ring<128, 128, 2, 2, 2, 0, 64, false, true>(a, vec, s) : launch_ring<128, 128, 2, 2, 2>(a, vec, s); break;
       case 5: rc = launch_ring<256, 128, 4, 2, 2>(a, vec, s); break;
       case 6: rc = launch_ring<128, 256, 2, 4, 3>(a, vec, s); break;
       case 7: rc = launch_pingpong(a, vec, s); break;

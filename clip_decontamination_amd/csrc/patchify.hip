@@ -49,7 +49,12 @@ int patchify(const sg_tile_batch& t, int P, void* out, int Kpad, int out_bf16, h
   SG_REQUIRE(t.n_tiles < 65536, "patchify: too many tiles in one launch");
   dim3 grid((unsigned)t.grid_h, (unsigned)t.n_tiles);
   const bool std_pad = Kpad == (3 * P * P + 63) / 64 * 64;
-  if (out_bf16 && std_pad && P == 14) hipLaunchKernelGGL((patchify_kernel<bf16_t, 14>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
+  if (out_bf16 == HK_F16) {
+    if (std_pad && P == 14) hipLaunchKernelGGL((patchify_kernel<f16_t, 14>), grid, dim3(256), 0, s, t, P, (f16_t*)out, Kpad);
+    else if (std_pad && P == 16) hipLaunchKernelGGL((patchify_kernel<f16_t, 16>), grid, dim3(256), 0, s, t, P, (f16_t*)out, Kpad);
+    else hipLaunchKernelGGL((patchify_kernel<f16_t, 0>), grid, dim3(256), 0, s, t, P, (f16_t*)out, Kpad);
+  }
+  else if (out_bf16 && std_pad && P == 14) hipLaunchKernelGGL((patchify_kernel<bf16_t, 14>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
   else if (out_bf16 && std_pad && P == 16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 16>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
   else if (out_bf16 && std_pad && P == 32) hipLaunchKernelGGL((patchify_kernel<bf16_t, 32>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);
   else if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 0>), grid, dim3(256), 0, s, t, P, (bf16_t*)out, Kpad);

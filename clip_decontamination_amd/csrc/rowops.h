@@ -48,6 +48,7 @@ struct AttnArgs {
   float* lse_out;                           // [B,H,N] or null; when ctx == null only the LSE pass runs
   bf16_t* ctx; int64_t ctx_sb, ctx_st;      // output [B,N,H*dv] bf16
   float out_scale;
+  int f16;                                  // operands and ctx are IEEE f16 instead of bf16 (SG_PREC_F16)
 };
 int attention_bf16(const AttnArgs& a, hipStream_t s);
 

@@ -17,6 +17,10 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
   uint2 o; o.x = pack_bf2(a, b); o.y = pack_bf2(c, d);
   *reinterpret_cast<uint2*>(p) = o;
 }
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float a, float b, float c, float d) {
+  uint2 o; o.x = pack_h2(a, b); o.y = pack_h2(c, d);
+  *reinterpret_cast<uint2*>(p) = o;
+}
 
 // Normalise the row held in v[] (nvec float4 per lane) -- reference LayerNorm/LayerNormFp32
 // (open_clip/transformer.py:17-32): biased variance, eps inside the sqrt, f32 arithmetic.
@@ -71,7 +75,8 @@ int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta
   SG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: row strides must be multiples of 4");
   if (rows == 0) return SG_OK;
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (y_is_bf16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, ldy, rows, D, eps);
+  if (y_is_bf16 == HK_F16) hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (f16_t*)y, ldy, rows, D, eps);
+  else if (y_is_bf16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, ldy, rows, D, eps);
   else hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (float*)y, ldy, rows, D, eps);
   SG_LAUNCH_CHECK();
   return SG_OK;
@@ -172,7 +177,8 @@ int quantize_rows_fp8(const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int
   SG_REQUIRE(D % 4 == 0 && ldy % 4 == 0, "quantize_rows_fp8: D=%d and the output stride must be multiples of 4", D);
   if (rows == 0) return SG_OK;
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (x_is_bf16) hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, y, ldy, scale, rows, D);
+  if (x_is_bf16 == HK_F16) hipLaunchKernelGGL(quantize_rows_fp8_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, ldx, y, ldy, scale, rows, D);
+  else if (x_is_bf16) hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, y, ldy, scale, rows, D);
   else hipLaunchKernelGGL(quantize_rows_fp8_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, y, ldy, scale, rows, D);
   SG_LAUNCH_CHECK();
   return SG_OK;
@@ -288,12 +294,13 @@ int posembed_resize(const float* pos, int g0, int D, int gh, int gw, int antiali
 }
 
 // ---- f32 -> bf16 pack with optional zero padding of the row (weights, patch matrix K padding) ------
-__global__ void pack_bf16_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld_src, bf16_t* __restrict__ dst,
+template <typename OutT>
+__global__ void pack_half_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld_src, OutT* __restrict__ dst,
                                  int cols_pad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols_pad) return;
   const int64_t r = i / cols_pad; const int c = (int)(i % cols_pad);
-  dst[i] = c < cols ? f2bf(src[r * ld_src + c]) : (bf16_t)0;
+  dst[i] = from_f32<OutT>(c < cols ? src[r * ld_src + c] : 0.f);
 }
 __global__ void pack_f32_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld_src, float* __restrict__ dst,
                                 int cols_pad) {
@@ -305,7 +312,8 @@ __global__ void pack_f32_kernel(const float* __restrict__ src, int64_t rows, int
 int pack_rows(const float* src, int64_t rows, int cols, int64_t ld_src, void* dst, int cols_pad, int to_bf16, hipStream_t s) {
   const int64_t total = rows * cols_pad;
   if (total == 0) return SG_OK;
-  if (to_bf16) hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (bf16_t*)dst, cols_pad);
+  if (to_bf16 == HK_F16) hipLaunchKernelGGL(pack_half_kernel<f16_t>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (f16_t*)dst, cols_pad);
+  else if (to_bf16) hipLaunchKernelGGL(pack_half_kernel<bf16_t>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (bf16_t*)dst, cols_pad);
   else hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (float*)dst, cols_pad);
   SG_LAUNCH_CHECK();
   return SG_OK;
@@ -317,7 +325,7 @@ __global__ void transpose_pack_kernel(const float* __restrict__ src, int rows, i
   if (i >= (int64_t)rows * cols) return;
   const int c = (int)(i / rows), r = (int)(i % rows);
   const float v = src[(int64_t)r * cols + c];
-  if (to_bf16) ((bf16_t*)dst)[i] = f2bf(v); else ((float*)dst)[i] = v;
+  if (to_bf16 == HK_F16) ((f16_t*)dst)[i] = f2h(v); else if (to_bf16) ((bf16_t*)dst)[i] = f2bf(v); else ((float*)dst)[i] = v;
 }
 int transpose_pack(const float* src, int rows, int cols, void* dst, int to_bf16, hipStream_t s) {
   hipLaunchKernelGGL(transpose_pack_kernel, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, rows, cols, dst, to_bf16);
@@ -340,14 +348,20 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const InT* __restrict_
   const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
   for (int i = lane; i < D; i += 64) yr[i] = from_f32<OutT>(to_f32<InT>(xr[i]) * inv);
 }
+template <typename InT>
+static void l2norm_launch_out(const InT* x, int64_t so, int64_t si, int inner, void* y, int y_kind, int64_t yo, int64_t yi, int64_t rows, int D,
+                              float eps, dim3 grid, hipStream_t s) {
+  if (y_kind == HK_F16) hipLaunchKernelGGL((l2norm_rows_kernel<InT, f16_t>), grid, dim3(256), 0, s, x, so, si, inner, (f16_t*)y, yo, yi, rows, D, eps);
+  else if (y_kind == HK_BF16) hipLaunchKernelGGL((l2norm_rows_kernel<InT, bf16_t>), grid, dim3(256), 0, s, x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps);
+  else hipLaunchKernelGGL((l2norm_rows_kernel<InT, float>), grid, dim3(256), 0, s, x, so, si, inner, (float*)y, yo, yi, rows, D, eps);
+}
 int l2norm_rows(const void* x, int x_bf16, int64_t so, int64_t si, int inner, void* y, int y_bf16, int64_t yo, int64_t yi,
                 int64_t rows, int D, float eps, hipStream_t s) {
   if (rows == 0) return SG_OK;
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (!x_bf16 && !y_bf16) hipLaunchKernelGGL((l2norm_rows_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, so, si, inner, (float*)y, yo, yi, rows, D, eps);
-  else if (!x_bf16 && y_bf16) hipLaunchKernelGGL((l2norm_rows_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps);
-  else if (x_bf16 && y_bf16) hipLaunchKernelGGL((l2norm_rows_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps);
-  else hipLaunchKernelGGL((l2norm_rows_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)x, so, si, inner, (float*)y, yo, yi, rows, D, eps);
+  if (x_bf16 == HK_F16) l2norm_launch_out<f16_t>((const f16_t*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
+  else if (x_bf16 == HK_BF16) l2norm_launch_out<bf16_t>((const bf16_t*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
+  else l2norm_launch_out<float>((const float*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }
@@ -467,7 +481,8 @@ __global__ __launch_bounds__(256) void head_norms_kernel(const T* __restrict__ x
 }
 int head_norms(const void* x, int is_bf16, int64_t sb, int64_t st, int B, int N, int H, int dh, float* out, hipStream_t s) {
   dim3 grid((unsigned)cdiv((int64_t)N * H, 4), (unsigned)B);
-  if (is_bf16) hipLaunchKernelGGL(head_norms_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, sb, st, N, H, dh, out);
+  if (is_bf16 == HK_F16) hipLaunchKernelGGL(head_norms_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, sb, st, N, H, dh, out);
+  else if (is_bf16) hipLaunchKernelGGL(head_norms_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, sb, st, N, H, dh, out);
   else hipLaunchKernelGGL(head_norms_kernel<float>, grid, dim3(256), 0, s, (const float*)x, sb, st, N, H, dh, out);
   SG_LAUNCH_CHECK();
   return SG_OK;

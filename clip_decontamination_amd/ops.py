@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F32, PREC_FP8, MODEL_TYPES, check
+from ._lib import PREC_BF16, PREC_F16, PREC_F32, PREC_FP8, MODEL_TYPES, check
 
 
 def _require_gpu(*tensors):
@@ -52,6 +52,8 @@ def precision_id(precision) -> int:
         return PREC_BF16
     if precision in (PREC_FP8, "fp8"):
         return PREC_FP8
+    if precision in (PREC_F16, "f16", "fp16", "half", torch.float16):
+        return PREC_F16
     raise ValueError(f"unknown precision {precision!r}")
 
 

@@ -33,7 +33,7 @@ class HipJBU:
             raise RuntimeError("HipJBU needs a GPU: the hot path has no CPU implementation")
         self.model_name, self.feat_dim = model_name, feat_dim
         self.device = torch.device(device)
-        self.precision = min(precision_id(precision), 1)          # the upsampler has no fp8 path: fp8 towers feed it in bf16 mode
+        self.precision = min(precision_id(precision), 1)          # the upsampler has no fp8 / f16 path: those towers feed it in bf16 mode
         self._ctx = C.c_void_p()
         self._ws = {}
         self.tiles_per_launch = 8            # tiles per JBU launch (workspace ~2.2 GB per 512-pixel tile)

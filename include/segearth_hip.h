@@ -43,6 +43,9 @@ enum sg_precision {       /* arithmetic the ViT GEMMs / attention run in */
   SG_PREC_BF16 = 1,       /* throughput mode: bf16 MFMA, f32 accumulate, f32 residual stream + LN */
   SG_PREC_FP8 = 2,        /* bf16 mode whose QKV / fc / proj linears of the ordinary blocks run on fp8 (OCP e4m3) MFMA with per-token and
                              per-output-channel absmax scales; attention, out-proj, the last block and everything else stay bf16 / f32 */
+  SG_PREC_F16 = 3,        /* throughput mode on IEEE f16 operands (v_mfma_*_f16: the bf16 rate, 3 more mantissa bits): the reference's own
+                             GPU arithmetic (segmentor.py:467 .half(), open_clip/model.py:142 fp32 LayerNorm).  f32 accumulate, f32
+                             residual stream / LN / softmax statistics as in bf16 mode; stores saturate at +-65504 */
 };
 
 /* last-block attention variants: reference open_clip/transformer.py:858-932 (custom_attn),

@@ -3,8 +3,9 @@
 oracle finishes in seconds on the GPU box's host cores; the kernels, shapes per tile and code paths are the configs' own.
 
 Tolerances: f32 parity mode  max|dlogit| < 1e-3 and label maps identical (north_star);
-            bf16 mode        max|dlogit| < 5e-2 and >= 97 % label agreement (reported).
-config 5 names fp8: no fp8 GEMM exists in this build yet, the case runs in f32 / bf16 and says so."""
+            bf16 / f16 modes bounded at about 2x the measured worst case (HALF_TOL below; measured values are printed).
+config 5 names fp8: its fp8 run (SG_PREC_FP8: QKV / fc / proj linears on v_mfma_scale_f32_16x16x128_f8f6f4) lives in
+tests/test_gpu_fp8.py; here the same case runs in f32 / bf16 / f16."""
 import os
 
 import numpy as np
@@ -18,6 +19,10 @@ from oracle import segment as OS, vit as OV, refine as OR          # checker onl
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
+
+
+# throughput modes: (max|dlogit|, label agreement) bounds = about 2x the worst measured over configs 2-5 (values printed per case)
+HALF_TOL = {"bf16": (5e-2, 0.97), "f16": (1e-2, 0.99)}
 
 
 def names(f):
@@ -65,10 +70,11 @@ def compare(seg, logits, ref_logits, oracle, tag, prec):
             thd = (pmax - oracle.prob_thd).abs() < 1e-4
             assert bool((tie | thd).all()), "label mismatch away from a tie"
     else:
-        assert err < 5e-2 and agree >= 0.97
+        tol_err, tol_agree = HALF_TOL[prec]
+        assert err < tol_err and agree >= tol_agree
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_config2_b16_512_slide_potsdam(prec):
     """configs[1]: ViT-B/16, 512 tiles at stride 256, Potsdam (8 queries / 6 classes), the shipped refiner stack."""
     kw = dict(model_type="Experimental", global_debias_factor=0.2, apply_similarity_enhancement=True, similarity_enhancement_cfg=SIM,
@@ -84,7 +90,7 @@ def test_config2_b16_512_slide_potsdam(prec):
     compare(seg, logits, ref, o, "config2 B/16 512-slide", prec)
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_config3_l14_gem_loveda(prec):
     """configs[2], GEM half: ViT-L/14 through segearth_segmentor.Segmentor(model_type='GEM') (the only reference class where GEM
     runs), LoveDA 9 queries / 7 classes."""
@@ -99,7 +105,7 @@ def test_config3_l14_gem_loveda(prec):
     compare(seg, logits, ref, o, "config3 L/14 GEM", prec)
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_config3_l14_outlier_loveda(prec):
     """configs[2], outlier-suppression half: ViT-L/14 SegmentorEx + OutlierSuppressionModule(top_k=30), LoveDA."""
     kw = dict(model_type="SegEarth", global_debias_factor=0.2, apply_outlier_suppression=True, outlier_suppression_cfg=dict(top_k=30),
@@ -114,7 +120,7 @@ def test_config3_l14_outlier_loveda(prec):
     compare(seg, logits, ref, o, "config3 L/14 outlier k=30", prec)
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_config4_l14_jbu_isaid(prec):
     """configs[3]: ViT-L/14 + SimFeatUp JBU (jbu_one, the shipped base config), iSAID 16 queries; per-pixel logits."""
     kw = dict(model_type="SegEarth", global_debias_factor=0.2, prob_thd=0.4, slide_crop=224, slide_stride=112, apply_sim_feat_up=True,
@@ -130,7 +136,7 @@ def test_config4_l14_jbu_isaid(prec):
     compare(seg, logits, ref, o, "config4 L/14 + JBU", prec)
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_config5_h14_cross_tile_fusion_xbd(prec):
     """configs[4] without its fp8 (not built): ViT-H/14 (erf-GELU, head dim 80), xBD 2 queries, CrossTileFusion('weighted') over a
     2 x 2 tile scene.  Oracle = per-tile oracle tokens -> the reference module's sequential semantics -> logits -> stitch."""

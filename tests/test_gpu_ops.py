@@ -33,7 +33,7 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(197, 192, 192), (64, 64, 64), (130, 260, 588), (2740, 3072, 1024), (1370, 1024, 4096), (33, 7, 50)])
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 3e-3)])
 def test_linear(ops, M, N, K, prec, tol):
     A, W, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
     for act in (0, 1, 2):
@@ -55,6 +55,8 @@ def test_linear_identity_asymmetric(ops):
     W = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) / 251.0
     out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="bf16")
     assert rel_err(out, W.T.bfloat16().float()) < 1e-6
+    out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="f16")
+    assert rel_err(out, W.T.half().float()) < 1e-6
     out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="f32")
     assert rel_err(out, W.T) < 1e-6
 
@@ -113,7 +115,7 @@ SHAPES = [(2, 37, 64, 2), (1, 197, 128, 2), (1, 300, 160, 2), (1, 1370, 128, 2),
 
 @pytest.mark.parametrize("B,N,D,H", SHAPES)
 @pytest.mark.parametrize("variant", ["vanilla", "ClearCLIP", "SCLIP", "SegEarth", "SFP", "Experimental"])
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
 def test_attention(ops, B, N, D, H, variant, prec, tol):
     qkv = rnd(B, N, 3 * D, seed=N + D, scale=1.0)
     sim = None
@@ -126,7 +128,7 @@ def test_attention(ops, B, N, D, H, variant, prec, tol):
 
 
 @pytest.mark.parametrize("variant", ["NACLIP", "NOnly", "GAV"])
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
 def test_attention_gaussian_window(ops, variant, prec, tol):
     """NACLIP / NOnly / GAV (reference open_clip/transformer.py:909-932): Gaussian neighbourhood bias, square grids."""
     for (B, g, D, H) in ((2, 6, 64, 2), (1, 14, 128, 2), (1, 37, 128, 2)):
@@ -137,7 +139,7 @@ def test_attention_gaussian_window(ops, variant, prec, tol):
         assert rel_err(out, ref) < tol, (variant, g, rel_err(out, ref))
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16", 3e-2), ("f16", 4e-3)])
 def test_attention_stats(ops, prec, tol):
     B, N, D, H = 2, 101, 128, 2
     qkv = rnd(B, N, 3 * D, seed=3)
@@ -149,11 +151,11 @@ def test_attention_stats(ops, prec, tol):
     assert rel_err(a_diag, torch.diagonal(am, dim1=-2, dim2=-1)) < tol
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("bf16", 1e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("bf16", 1e-2), ("f16", 1.5e-3)])
 def test_similarity_map(ops, golden, prec, tol):
     g = golden("refine")
     f = torch.from_numpy(g["sim_feats"])
-    if prec == "bf16":                       # bf16 GEMM needs D % 64 == 0
+    if prec != "f32":                        # the half-precision GEMM needs D % 64 == 0
         f = torch.cat([f, torch.zeros(*f.shape[:2], 24)], -1)
     a = ops.similarity_map(f.to(DEV), 1.0, True, prec)
     b = ops.similarity_map(f.to(DEV), 0.5, False, prec)

@@ -32,16 +32,18 @@ def test_text_golden_f32(golden, name):
     assert (outn - torch.from_numpy(g["features_normalized"])).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("prec,bound", [("bf16", 0.999), ("f16", 0.99998)])
 @pytest.mark.parametrize("name", ["tiny-text", "tiny-text-gelu"])
-def test_text_golden_bf16(golden, name):
+def test_text_golden_bf16(golden, name, prec, bound):
     g = golden(f"text_{name}")
-    tc, tt = tower(name, "bf16")
+    tc, tt = tower(name, prec)
     out = tt.encode_text(torch.from_numpy(g["tokens"])).cpu()
     cos = F.cosine_similarity(out, torch.from_numpy(g["features"]), dim=-1)
-    assert cos.min().item() > 0.999, cos
+    print(f"[{prec}] text {name}: min cosine {cos.min().item():.7f}")
+    assert cos.min().item() > bound, cos
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", None)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", None), ("f16", None)])
 def test_text_real_shape_vs_oracle(prec, tol):
     """ViT-B/16's text tower (512 wide, 12 layers, 77 tokens, 49408 ids) on 24 tokenizer-shaped rows."""
     tc, tt = tower("ViT-B-16", prec)
@@ -52,7 +54,9 @@ def test_text_real_shape_vs_oracle(prec, tol):
     if tol is not None:
         assert (out - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
     else:
-        assert F.cosine_similarity(out, ref, dim=-1).min().item() > 0.998
+        cmin = F.cosine_similarity(out, ref, dim=-1).min().item()
+        print(f"[{prec}] text ViT-B/16: min cosine {cmin:.7f}")
+        assert cmin > (0.998 if prec == "bf16" else 0.99995)
 
 
 def test_causality_and_padding_independence():

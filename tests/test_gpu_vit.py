@@ -15,6 +15,12 @@ from clip_decontamination_amd import weights as Wt            # noqa: E402
 from oracle import vit as OV, segment as OS                    # noqa: E402  (checker only)
 
 DEV = "cuda:0"
+# Throughput-mode bounds = about 2x the measured worst case on MI355X (gpurun logs of round 2; the measured value is printed by every
+# test).  bf16 has 8 significant bits, f16 has 11: the f16 bounds are ~8x tighter.
+HALF_TOL = {
+    "bf16": dict(tiny_tokens=0.06, gem=0.06, real_err=0.15, real_q99=1e-2, real_agree=0.90, sa_attn=0.08),
+    "f16": dict(tiny_tokens=0.012, gem=0.012, real_err=0.03, real_q99=2e-3, real_agree=0.97, sa_attn=0.02),
+}
 POTSDAM_QIDX = [0, 0, 1, 2, 3, 4, 5, 5]
 SIM = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
 
@@ -41,9 +47,12 @@ def tiny_f32():
     return tower("tiny-8", "f32")
 
 
-@pytest.fixture(scope="module")
-def tiny_bf16():
-    return tower("tiny-8", "bf16")
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def tiny_bf16(request):
+    """The tiny tower in a throughput mode: bf16 or f16 operands (SG_PREC_BF16 / SG_PREC_F16)."""
+    cfg, net = tower("tiny-8", request.param)
+    net.precision_tag = request.param
+    return cfg, net
 
 
 @pytest.mark.parametrize("mt", ["vanilla", "MaskCLIP", "ClearCLIP", "SCLIP", "SegEarth", "SFP", "Experimental", "NACLIP", "NOnly", "GAV"])
@@ -69,7 +78,9 @@ def test_tiny_model_types_bf16(golden, tiny_bf16, mt):
         img = img[:1]
     cls, tok = net.encode_image(img.to(DEV), mt, True, output_cls_token=True)
     ref = torch.from_numpy(g[f"{mt}.tokens"])
-    assert maxdiff(tok, ref) < 0.06 * ref.abs().max().item()
+    rel = maxdiff(tok, ref) / ref.abs().max().item()
+    print(f"[{net.precision_tag}] tiny {mt}: max rel token error {rel:.3e}")
+    assert rel < HALF_TOL[net.precision_tag]["tiny_tokens"]
 
 
 def test_tiny_residual_native_gelu_f32(golden, tiny_f32):
@@ -106,7 +117,7 @@ def test_tiny_refiners_f32(golden, tiny_f32, tag, mt):
     assert maxdiff(cls, g[f"{tag}.{mt}.cls"]) < 1e-4
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", None)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", None), ("f16", None)])
 def test_tiny_gem(golden, prec, tol):
     cfg, net = tower("tiny-gem", prec)
     g = golden("vit_tiny-gem")
@@ -115,7 +126,8 @@ def test_tiny_gem(golden, prec, tol):
         for nm in ("g6", "g4"):
             tok = net.visual(torch.from_numpy(g[f"{nm}.img"]).to(DEV))
             ref = torch.from_numpy(g[f"{nm}.ign{int(ign)}.tokens"])
-            bound = tol if tol is not None else 0.06 * ref.abs().max().item()
+            bound = tol if tol is not None else HALF_TOL[prec]["gem"] * ref.abs().max().item()
+            print(f"[{prec}] GEM {nm} ign={ign}: max rel error {maxdiff(tok, ref) / ref.abs().max().item():.3e}")
             assert maxdiff(tok, ref) < bound, (prec, ign, nm, maxdiff(tok, ref))
 
 
@@ -148,10 +160,11 @@ def test_real_size_parity_f32(golden, vit, S):
         assert agree == 1.0
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("vit,S", [("ViT-B-16", 224), ("ViT-L-14", 512)])
-def test_real_size_parity_bf16(golden, vit, S):
-    """Throughput mode: report max|dlogit| and arg-max agreement against the fp32 reference fixture."""
-    cfg, net = tower(vit, "bf16")
+def test_real_size_parity_bf16(golden, vit, S, prec):
+    """Throughput modes: report max|dlogit| and arg-max agreement against the fp32 reference fixture."""
+    cfg, net = tower(vit, prec)
     install(net, SIM, dict(top_k=30))
     g = golden("real_logits")
     text = torch.from_numpy(Wt.make_text_features(8, cfg.embed_dim)).to(DEV)
@@ -159,17 +172,17 @@ def test_real_size_parity_bf16(golden, vit, S):
     pad = OS.compute_padsize(S, S, cfg.patch)
     imgp = (F.pad(img, pad) if any(pad) else img).to(DEV)
     for mt in ("SegEarth", "Experimental"):
-        lg = head_logits(net, cfg, imgp, mt, text, "bf16")[0]
+        lg = head_logits(net, cfg, imgp, mt, text, prec)[0]
         ref = torch.from_numpy(g[f"{vit}.{S}.{mt}.logits"])
         err = maxdiff(lg, ref)
         agree = (lg.argmax(0).cpu().to(torch.uint8) == torch.from_numpy(g[f"{vit}.{S}.{mt}.argmax"])).float().mean().item()
         q99 = torch.quantile((lg.cpu() - ref).abs().flatten(), 0.99).item()
-        print(f"[bf16] {vit}@{S} {mt}: max|dlogit| = {err:.2e}, 99th percentile = {q99:.2e}, argmax agreement = {agree:.4f}")
+        print(f"[{prec}] {vit}@{S} {mt}: max|dlogit| = {err:.2e}, 99th percentile = {q99:.2e}, argmax agreement = {agree:.4f}")
         # the maximum is set by discrete events (an outlier top-k pick that flips under bf16 rounding replaces a whole token), so it is
         # bounded loosely; the bulk of the error is what bf16 operands must deliver
-        assert err < 0.15
-        assert q99 < 1e-2
-        assert agree > 0.90
+        assert err < HALF_TOL[prec]["real_err"]
+        assert q99 < HALF_TOL[prec]["real_q99"]
+        assert agree > HALF_TOL[prec]["real_agree"]
 
 
 def test_u8_ingest_equals_float_ingest():
@@ -212,4 +225,5 @@ def test_tiny_selfattn_attention_mode_bf16(golden, tiny_bf16, mt):
     g = golden("vit_tiny-8")
     cls, tok = net.encode_image(torch.from_numpy(g["img"]).to(DEV), mt, True, output_cls_token=True, apply_similarity_enhancement=True)
     ref = torch.from_numpy(g[f"sa_attn.{mt}.tokens"])
-    assert maxdiff(tok, ref) < 0.08 * ref.abs().max().item()
+    print(f"[{net.precision_tag}] sa_attn {mt}: max rel error {maxdiff(tok, ref) / ref.abs().max().item():.3e}")
+    assert maxdiff(tok, ref) < HALF_TOL[net.precision_tag]["sa_attn"] * ref.abs().max().item()
