@@ -139,10 +139,11 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
           if constexpr (F16) {
-            f16x8 hq = __builtin_bit_cast(f16x8, qf[t][ks]);
+            const f16x8 hq = __builtin_bit_cast(f16x8, qf[t][ks]);
+            f32x8_t fq;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) hq[j] = (_Float16)((float)hq[j] * c2);
-            qf[t][ks] = __builtin_bit_cast(bf16x8, hq);
+            for (int j = 0; j < 8; ++j) fq[j] = (float)hq[j] * c2;
+            qf[t][ks] = __builtin_bit_cast(bf16x8, __builtin_convertvector(fq, f16x8));
           } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[t][ks][j] = (__bf16)((float)qf[t][ks][j] * c2);
@@ -180,7 +181,15 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-          float bvv = (key >= 1 && key < a.N && q_ld >= 1) ? a.bias[(int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1)] : 0.f;
+          float bvv = 0.f;
+          if (key >= 1 && key < a.N && q_ld >= 1) {
+            const int64_t off = (int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1);
+            if (a.bias_kind == HK_F32) bvv = a.bias[off];
+            else {
+              const bf16_t raw = reinterpret_cast<const bf16_t*>(a.bias)[off];
+              bvv = a.bias_kind == HK_F16 ? h2f(f16_t{raw}) : bf2f(raw);
+            }
+          }
           if (a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
           bnext[i] = bvv;
         }
@@ -315,10 +324,10 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         if constexpr (F16) {
-          f16x8 hp;
+          f32x8_t fp;                                        // 4 x v_cvt_pk_f16_f32
 #pragma unroll
-          for (int j = 0; j < 8; ++j) hp[j] = (_Float16)sc[8 * f + j];
-          pf[f] = __builtin_bit_cast(bf16x8, hp);
+          for (int j = 0; j < 8; ++j) fp[j] = sc[8 * f + j];
+          pf[f] = __builtin_bit_cast(bf16x8, __builtin_convertvector(fp, f16x8));
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];

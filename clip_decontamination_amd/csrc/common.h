@@ -83,7 +83,14 @@ __device__ __forceinline__ f16_t f2h(float f) {
   const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -F16_MAX, F16_MAX);   // round-to-nearest-even; NaN stays NaN
   f16_t o; __builtin_memcpy(&o.bits, &h, 2); return o;
 }
-__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) { return (uint32_t)f2h(lo).bits | ((uint32_t)f2h(hi).bits << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+// two f32 -> packed f16 (one v_cvt_pk_f16_f32, round-to-nearest-even) behind two saturating v_med3_f32
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  const f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -F16_MAX, F16_MAX), __builtin_amdgcn_fmed3f(hi, -F16_MAX, F16_MAX)};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
 // half-precision kind of a buffer / kernel: 0 = f32, 1 = bf16, 2 = f16 (every `int ..._bf16` flag of the internal ops takes these values)
 enum HalfKind { HK_F32 = 0, HK_BF16 = 1, HK_F16 = 2 };
 template <bool F16> __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) { return F16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); }
@@ -147,8 +154,12 @@ struct GemmBf16Args {
   // fp8 mode (fp8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K % 128 == 0); lda / ldw / K stay in ELEMENTS (= bytes);
   // the accumulator is de-quantised with row_scale[m] * col_scale[n] (per-token / per-output-channel absmax scales).
   int fp8; const float* row_scale; const float* col_scale;
+  // persistent kernel only: start-up stagger in shader cycles (0 = none).  Workgroup w sleeps phase(w) * stagger cycles before its
+  // first tile so that the HBM-heavy epilogues of the 256 workgroups (all tiles take the same time) do not all fall together.
+  int stagger;
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
+void set_gemm_tuning(int key, int value);   // tuning hook (per calling thread): key 0 = stagger cycles override (-1 = automatic)
 void set_gemm_config(int c);   // tuning hook (per calling thread): -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
 
 // f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];

@@ -22,7 +22,8 @@ SIM = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
 
 
 # throughput modes: (max|dlogit|, label agreement) bounds = about 2x the worst measured over configs 2-5 (values printed per case)
-HALF_TOL = {"bf16": (5e-2, 0.97), "f16": (1e-2, 0.99)}
+# measured (r2): bf16 max|dlogit| <= 1.4e-3, agreement >= 0.9947;  f16 <= 1.1e-4 (3.3e-4 with the bf16 JBU of config 4), >= 0.9992
+HALF_TOL = {"bf16": (3e-3, 0.989), "f16": (7e-4, 0.998)}
 
 
 def names(f):

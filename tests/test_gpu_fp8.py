@@ -120,4 +120,4 @@ def test_config5_h14_fp8_cross_tile_fusion_xbd():
     err = (logits.cpu() - canvas).abs().max().item()
     agree = (pred == ref_pred).float().mean().item()
     print(f"[config5 H/14 fp8 + cross-tile fusion] max|dlogit| = {err:.2e}, label agreement = {agree:.4f}")
-    assert err < 0.1 and agree > 0.9
+    assert err < 6e-3 and agree > 0.96                      # measured (r2): 2.6e-3, 0.981

@@ -309,7 +309,7 @@ def test_jbu_on_the_trained_checkpoint(golden, precision):
     err = (out[:64] - torch.from_numpy(g["out_c64"])).abs().max().item() / scale
     err_sq = ((out * out).sum(0) - torch.from_numpy(g["out_sq"])).abs().max().item() / float(np.abs(g["out_sq"]).max())
     print(f"jbu_stack trained weights [{precision}]: max rel err {err:.3e}, energy rel err {err_sq:.3e}")
-    tol = 2e-4 if precision == "f32" else 2e-2
+    tol = 2e-4 if precision == "f32" else 1.2e-2            # measured (r2): f32 6e-7; bf16 5.0e-3 / 5.6e-3
     assert err < tol and err_sq < tol, (err, err_sq)
 
 

@@ -62,8 +62,8 @@ def test_bench_launch_shape_128_tiles_equals_single_tile_launches(pipe):
             alone = pipe.tile_logits(scene, [wins[i]], (512, 512))[0]
             d = (batched[i] - alone).abs().max().item()
             worst = max(worst, d)
-            assert d < 1e-3, (i, d)
-            assert (batched[i].argmax(0) == alone.argmax(0)).float().mean().item() > 0.999, i
+            assert d < 1e-5, (i, d)                                # measured (r2): bit-identical (same kernels, same K order per element)
+            assert torch.equal(batched[i].argmax(0), alone.argmax(0)), i
         print(f"128-tile launch vs single-tile launches: max|dlogit| = {worst:.3e}")
         again = pipe.tile_logits(scene, wins, (512, 512))
         assert torch.equal(again, batched)                         # deterministic at the bench launch shape

@@ -32,7 +32,7 @@ def test_text_golden_f32(golden, name):
     assert (outn - torch.from_numpy(g["features_normalized"])).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("prec,bound", [("bf16", 0.999), ("f16", 0.99998)])
+@pytest.mark.parametrize("prec,bound", [("bf16", 0.9999), ("f16", 0.999998)])
 @pytest.mark.parametrize("name", ["tiny-text", "tiny-text-gelu"])
 def test_text_golden_bf16(golden, name, prec, bound):
     g = golden(f"text_{name}")
@@ -56,7 +56,7 @@ def test_text_real_shape_vs_oracle(prec, tol):
     else:
         cmin = F.cosine_similarity(out, ref, dim=-1).min().item()
         print(f"[{prec}] text ViT-B/16: min cosine {cmin:.7f}")
-        assert cmin > (0.998 if prec == "bf16" else 0.99995)
+        assert cmin > (0.99995 if prec == "bf16" else 0.999999)          # measured (r2): 0.99998 / 0.9999996
 
 
 def test_causality_and_padding_independence():

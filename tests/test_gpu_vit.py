@@ -17,9 +17,11 @@ from oracle import vit as OV, segment as OS                    # noqa: E402  (ch
 DEV = "cuda:0"
 # Throughput-mode bounds = about 2x the measured worst case on MI355X (gpurun logs of round 2; the measured value is printed by every
 # test).  bf16 has 8 significant bits, f16 has 11: the f16 bounds are ~8x tighter.
+# measured (r2): bf16 tiny tokens <= 8.8e-3, GEM 7.4e-3, real-size max|dlogit| 6.9e-2 (B/16@224: an outlier top-k pick that flips under
+# rounding replaces a whole token) / q99 4.0e-3 / agreement >= 0.9847, sa_attn 7.7e-3;  f16: 1.1e-3, 1.2e-3, 1.06e-4 / 7.8e-5 / 1.0000, 1.0e-3
 HALF_TOL = {
-    "bf16": dict(tiny_tokens=0.06, gem=0.06, real_err=0.15, real_q99=1e-2, real_agree=0.90, sa_attn=0.08),
-    "f16": dict(tiny_tokens=0.012, gem=0.012, real_err=0.03, real_q99=2e-3, real_agree=0.97, sa_attn=0.02),
+    "bf16": dict(tiny_tokens=0.018, gem=0.015, real_err=0.14, real_q99=8e-3, real_agree=0.97, sa_attn=0.016),
+    "f16": dict(tiny_tokens=2.2e-3, gem=2.5e-3, real_err=2.5e-4, real_q99=1.6e-4, real_agree=0.9995, sa_attn=2.2e-3),
 }
 POTSDAM_QIDX = [0, 0, 1, 2, 3, 4, 5, 5]
 SIM = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
