@@ -88,6 +88,7 @@ SIGNATURES = {
     "sg_jbu_set_tensor": (I, [P, C.c_char_p, P, L, P]),
     "sg_jbu_workspace_bytes": (Z, [P, I, I, I]),
     "sg_jbu_upsample": (I, [P, P, P, I, I, I, I, I, I, P, P, Z, P]),
+    "sg_jbu_logits": (I, [P, P, P, I, I, I, I, I, I, P, I, P, F, P, P, Z, P]),
     "sg_extract_tiles": (I, [C.POINTER(TileBatch), I, I, P, P]),
     "sg_global_debias": (I, [P, P, I, I, I, F, P, P]),
 }

@@ -154,6 +154,10 @@ struct GemmBf16Args {
   // fp8 mode (fp8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K % 128 == 0); lda / ldw / K stay in ELEMENTS (= bytes);
   // the accumulator is de-quantised with row_scale[m] * col_scale[n] (per-token / per-output-channel absmax scales).
   int fp8; const float* row_scale; const float* col_scale;
+  // persistent kernel only: row-dot epilogue.  With v = alpha * acc + bias and r = residual, NOTHING is stored to C; instead
+  // rowdot[m * rowdot_ld + n / 64] = sum over the 64 columns [n, n + 64) of v * (2 r + v)  (= |r + v|^2 - |r|^2 of that column slice):
+  // the JBU tail needs only the norm of x + 0.1 * conv1x1(x), never the C x S^2 map itself.  f32 residual required.
+  float* rowdot; int64_t rowdot_ld;
   // persistent kernel only: start-up stagger in shader cycles (0 = none).  Workgroup w sleeps phase(w) * stagger cycles before its
   // first tile so that the HBM-heavy epilogues of the 256 workgroups (all tiles take the same time) do not all fall together.
   int stagger;

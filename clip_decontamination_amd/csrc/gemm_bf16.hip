@@ -839,6 +839,14 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           const int r = r0 + lane / LPR, cq = (lane % LPR) * 4;
           const int m = rbase + r, n = col0 + cq;
           float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          if (a.rowdot) {                                    // row-dot epilogue (wave-uniform): v * (2 r + v) summed over this wave's 64 columns
+            const float4 rr = rbuf[t % RD][r0 / RPP];
+            float d = x.x * (2.f * rr.x + x.x) + x.y * (2.f * rr.y + x.y) + x.z * (2.f * rr.z + x.z) + x.w * (2.f * rr.w + x.w);
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+            if ((lane % LPR) == 0 && m < a.M) a.rowdot[(int64_t)m * a.rowdot_ld + (col0 >> 6)] = d;
+            continue;
+          }
           if (pipe_res) {
             const float4 rr = rbuf[t % RD][r0 / RPP];
             x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
@@ -1057,7 +1065,11 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   if (a.residual) vec = vec && (a.ldr % 4 == 0) && ((((uintptr_t)a.residual) & 15) == 0);
   (void)csz;
   SG_REQUIRE(a.act >= 0 && a.act <= 2, "gemm_bf16: bad act %d", a.act);
+  if (a.rowdot)
+    SG_REQUIRE(vec && a.residual && !a.c_is_bf16 && a.batch == 1 && a.M >= 1024 && a.N >= 512 && a.N % 64 == 0 && a.K / 32 >= 4,
+               "gemm_bf16: the row-dot epilogue needs the persistent kernel (M >= 1024, N >= 512, N %% 64 == 0), an f32 residual and batch 1");
   int cfg = g_gemm_config;
+  if (a.rowdot) cfg = 30;
   if (cfg < 0 || a.f16) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
   if (cfg > 0) {
     const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? PROF_GEMM_PERSIST : PROF_GEMM_BF16;

@@ -361,6 +361,181 @@ __global__ __launch_bounds__(256) void jbu_adaptive_conv_mfma_kernel(const bf16_
   }
 }
 
+
+// ---- adaptive convolution on the LOW-RES source (throughput mode, radius 5 / 3) -------------------------------------------------
+// hr = bicubic2x(src) is linear in src, so   out[p] = sum_t K[p,t] hr[p+t] = sum_s Keff[p,s] src[s]   with
+//     Keff = Wy^T . K . Wx        (Wy / Wx: the 4-tap bicubic rows of the reflect-padded hi-res tap rows / columns of the pixel)
+// over a LW x LW low-res window (12 x 12 at r = 5, 10 x 10 at r = 3) instead of the (8+2r)^2 hi-res window: the bicubic kernel, the
+// hi-res tensor and half of the GEMM's K dimension disappear (K 352 -> 160 at r = 5).  Per 8 x 8 pixel block:
+//   1. Wx / Wy tables (dense [8][D][12] f32) from the same cubic_taps() arithmetic as jbu_bicubic_kernel, K rows of the 64 pixels -> LDS
+//   2. Keff per pixel on the VALU: 4 threads per pixel, thread q owns window columns 3q..3q+2: T = K . Wx (registers), Keff = Wy^T . T
+//      -> F [64 px][KP] bf16 (K contiguous)                                  [3 k FMA per pixel, shared by all C channels]
+//   3. per 128-channel chunk: window [pos][128 ch] bf16 copied as it lies in HBM (16-byte pieces, no transposition); the MFMA operand
+//      (8 consecutive window positions of one channel per lane) is fetched with two ds_read_b64_tr_b16 (hardware transpose);
+//      out[64, 128] = F . Win on v_mfma_f32_16x16x32_bf16, operands swapped so a lane owns 4 consecutive channels of one pixel.
+// 65 KB of LDS: two blocks per CU overlap each other's staging and MFMA phases.
+template <int R> struct LowCfg {
+  static constexpr int D = 2 * R + 1, D2 = D * D;
+  static constexpr int LW = R == 5 ? 12 : 10;          // low-res window side
+  static constexpr int LWP = 12;                        // padded to 4 threads x 3 columns
+  static constexpr int OFF = R == 5 ? 4 : 3;            // window origin = block origin / 2 - OFF
+  static constexpr int NPOS = LW * LW;
+  static constexpr int KP = (NPOS + 31) / 32 * 32;
+  static constexpr int LDK = KP + 8;                    // F row stride (bf16)
+  static constexpr int LDW = ACM_CC + 16;               // window row stride (bf16): [pos][ch]; 288 B keeps the 4-row transposed reads on distinct banks
+  static constexpr size_t F_BYTES = (size_t)64 * LDK * 2;
+  static constexpr size_t W_BYTES = (size_t)KP * LDW * 2;
+  static constexpr size_t K_BYTES = (size_t)64 * D2 * 4 + (size_t)2 * 8 * D * LWP * 4;
+  static constexpr size_t LDS = F_BYTES + (W_BYTES > K_BYTES ? W_BYTES : K_BYTES);
+};
+
+template <int R>
+__global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* __restrict__ src, const float* __restrict__ Kf, int ldk, int h, int w,
+                                                                 int C, float* __restrict__ out, bf16_t* __restrict__ out16) {
+  using L = LowCfg<R>;
+  constexpr int D = L::D, D2 = L::D2, LW = L::LW, LWP = L::LWP, KP = L::KP, LDK = L::LDK, LDW = L::LDW;
+  extern __shared__ __attribute__((aligned(16))) char lc_sm[];
+  bf16_t* sF = reinterpret_cast<bf16_t*>(lc_sm);                          // [64][LDK]
+  bf16_t* sW = reinterpret_cast<bf16_t*>(lc_sm + L::F_BYTES);            // [KP][LDW]            (chunk loop)
+  float* sK = reinterpret_cast<float*>(lc_sm + L::F_BYTES);              // [64][D2]             (Keff build; aliases sW)
+  float* sWx = sK + 64 * D2;                                              // [8][D][LWP]
+  float* sWy = sWx + 8 * D * LWP;
+  const int H = 2 * h, W = 2 * w;
+  const int tiles_x = (W + AC_T - 1) / AC_T;
+  const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+  const int ty0 = (blk / tiles_x) * AC_T, tx0 = (blk % tiles_x) * AC_T;
+  const int ly0 = ty0 / 2 - L::OFF, lx0 = tx0 / 2 - L::OFF;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- 1. tables + the block's kernel rows ----
+  if (tid < 2 * 8 * D) {
+    const bool isy = tid >= 8 * D;
+    const int e = isy ? tid - 8 * D : tid, pl = e / D, t = e % D;
+    const int size = isy ? H : W, lo_size = isy ? h : w, org = isy ? ty0 : tx0, lorg = isy ? ly0 : lx0;
+    int u = org + pl + t - R;
+    u = u > size - 1 + R ? size - 1 + R : u;                               // ragged last block: stay inside the padded image
+    u = reflect_idx(u, size);
+    int idx[4]; float wt[4];
+    cubic_taps(u, lo_size, size, idx, wt);
+    float* row = (isy ? sWy : sWx) + (pl * D + t) * LWP;
+#pragma unroll
+    for (int c = 0; c < LWP; ++c) row[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int c = idx[k] - lorg;
+      c = c < 0 ? 0 : (c > LW - 1 ? LW - 1 : c);                           // by construction already inside the window
+      row[c] += wt[k];
+    }
+  }
+  for (int i = tid; i < D2 * 64; i += 256) {
+    const int pxl = i / D2, t = i % D2;                                    // coalesced along the taps of one pixel
+    int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+    y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+    sK[pxl * D2 + t] = Kf[(((int64_t)b * H + y) * W + x) * ldk + t];
+  }
+  __syncthreads();
+  // ---- 2. Keff = Wy^T . K . Wx for pixel p, window columns 3q..3q+2 ----
+  {
+    const int p = tid >> 2, q = tid & 3, py = p >> 3, px = p & 7;
+    const float* kp = sK + p * D2;
+    const float* wx = sWx + px * D * LWP + 3 * q;
+    const float* wy = sWy + py * D * LWP;
+    float T[D][3];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float kv = kp[i * D + j];
+        t0 += kv * wx[j * LWP]; t1 += kv * wx[j * LWP + 1]; t2 += kv * wx[j * LWP + 2];
+      }
+      T[i][0] = t0; T[i][1] = t1; T[i][2] = t2;
+    }
+    float e[LW][3];
+#pragma unroll
+    for (int ly = 0; ly < LW; ++ly) { e[ly][0] = 0.f; e[ly][1] = 0.f; e[ly][2] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int ly = 0; ly < LW; ++ly) {
+        const float wv = wy[i * LWP + ly];
+        e[ly][0] += wv * T[i][0]; e[ly][1] += wv * T[i][1]; e[ly][2] += wv * T[i][2];
+      }
+    bf16_t* fr = sF + p * LDK;                                             // F does not alias sK / the tables
+#pragma unroll
+    for (int ly = 0; ly < LW; ++ly)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (3 * q + c < LW) fr[ly * LW + 3 * q + c] = f2bf(e[ly][c]);
+    for (int k = L::NPOS + q; k < KP; k += 4) fr[k] = 0;                   // K padding
+  }
+  const bf16_t* sb = src + (int64_t)b * h * w * C;
+  for (int c0 = 0; c0 < C; c0 += ACM_CC) {
+    __syncthreads();                                                       // F complete / Keff build done with sK / previous chunk's MFMAs done with sW
+    // ---- 3a. window [pos][128 ch] as it lies in HBM: 16 x 16-byte pieces per position ----
+    for (int i = tid; i < KP * (ACM_CC / 8); i += 256) {
+      const int pos = i / (ACM_CC / 8), qc = i % (ACM_CC / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pos < L::NPOS && c0 + 8 * qc < C) {
+        int sy = ly0 + pos / LW, sx = lx0 + pos % LW;
+        sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy); sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);   // weight 0 outside: any finite value
+        v = *reinterpret_cast<const uint4*>(sb + ((int64_t)sy * w + sx) * C + c0 + 8 * qc);
+      }
+      *reinterpret_cast<uint4*>(sW + pos * LDW + 8 * qc) = v;
+    }
+    __syncthreads();
+    // ---- 3b. wave: channels [32 wave, +32) x 64 pixels ----
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((ext_vector_type(4))) short s4_t;
+    typedef __attribute__((address_space(3))) s4_t* lds_s4_t;
+    typedef __attribute__((ext_vector_type(8))) short s8_t;
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;         // transposed read: lane 4q+p of a 16-lane group addresses row q, cols 4p..4p+3
+#pragma unroll 1
+    for (int k0 = 0; k0 < KP; k0 += 32) {
+      bf16x8 fa[4], fw[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(sF + (mi * 16 + (lane & 15)) * LDK + k0 + g * 8);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        const bf16_t* p0 = sW + (k0 + 8 * g + qq) * LDW + wave * 32 + nj * 16 + 4 * pp;
+        const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(p0));
+        const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(p0 + 4 * LDW));
+        const s8_t both = (s8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fw[nj] = __builtin_bit_cast(bf16x8, both);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nj], fa[mi], acc[mi][nj], 0, 0, 0);
+    }
+    // lane: pixel mi*16 + (lane & 15), channels c0 + 32 wave + 16 nj + 4 (lane >> 4) .. +4
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int pxl = mi * 16 + (lane & 15);
+      const int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+      if (y < H && x < W) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          const int c = c0 + wave * 32 + nj * 16 + (lane >> 4) * 4;
+          if (c < C) {
+            const int64_t o = (((int64_t)b * H + y) * W + x) * C + c;
+            if (out) *reinterpret_cast<float4*>(out + o) = make_float4(acc[mi][nj][0], acc[mi][nj][1], acc[mi][nj][2], acc[mi][nj][3]);
+            if (out16) {
+              uint2 qv; qv.x = pack_bf2(acc[mi][nj][0], acc[mi][nj][1]); qv.y = pack_bf2(acc[mi][nj][2], acc[mi][nj][3]);
+              *reinterpret_cast<uint2*>(out16 + o) = qv;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // Stand-alone adaptive convolution in FeatUp's NCHW calling convention
 // (featup.adaptive_conv_cuda.AdaptiveConv.apply as used at upsamplers.py:274; semantics restated from
 // adaptive_conv_py_simple, upsamplers.py:14-25):  out[b,c,y,x] = sum_{i,j<d} in[b,c,y+i,x+j] * filt[b,y,x,i,j]
@@ -529,7 +704,8 @@ extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, 
 }
 
 namespace sg {
-struct JbuPlan { float *gs, *proj, *X, *H1, *Kf, *hr, *bufA, *bufB; void* x16; bf16_t *X16, *H116; };
+struct JbuPlan { float *gs, *proj, *X, *H1, *Kf, *hr, *bufA, *bufB; void* x16; bf16_t *X16, *H116; float *rowdot, *geff, *g0, *clsl; };
+constexpr int JBU_QMAX = 32;                         // queries the fused logits tail keeps in registers
 static size_t jbu_plan(const sg_jbu* j, int B, int gh, int gw, void* ws, bool dry, JbuPlan& p) {
   const int r = j->st[0].r, d2 = (2 * r + 1) * (2 * r + 1);
   const int64_t pixels = (int64_t)B * 16 * gh * 16 * gw;              // final resolution
@@ -547,6 +723,10 @@ static size_t jbu_plan(const sg_jbu* j, int B, int gh, int gw, void* ws, bool dr
   p.bufA = (float*)take((size_t)pixels / 4 * j->C * 4);                // stage-3 output (8x): ping
   p.bufB = (float*)take((size_t)pixels * j->C * 4);                    // stage-2 / stage-4 output: pong
   p.x16 = take((size_t)pixels * j->C * 2);
+  p.rowdot = (float*)take((size_t)pixels * (j->C / 64 + 1) * 4);       // fused tail: per-pixel partial |out|^2 - |x|^2, one slot per 64 columns
+  p.geff = (float*)take((size_t)j->C * JBU_QMAX * 4);
+  p.g0 = (float*)take((size_t)JBU_QMAX * 4);
+  p.clsl = (float*)take((size_t)B * JBU_QMAX * 4);
   return align_up(off, 256);
 }
 }  // namespace sg
@@ -557,19 +737,21 @@ extern "C" size_t sg_jbu_workspace_bytes(const sg_jbu* j, int B, int gh, int gw)
   return jbu_plan(j, B, gh, gw, nullptr, true, p);
 }
 
-// source [B, gh*gw, C] (patch tokens), guidance [B,3,GH,GW] (the normalised, padded tile) -> out [B, (16gh*16gw), C]
-extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
-                               float* out, void* ws, size_t ws_bytes, sg_stream st) {
-  SG_REQUIRE(j && source && guidance && out && ws, "sg_jbu_upsample: null argument");
-  for (size_t i = 0; i < j->have.size(); ++i) if (!j->have[i]) return fail(SG_ERR_STATE, "sg_jbu_upsample: upsampler weights incomplete");
-  DeviceGuard dg(j->device);
-  hipStream_t s = as_stream(st);
-  JbuPlan p;
-  const size_t need = jbu_plan(j, B, gh, gw, ws, false, p);
-  if (need > ws_bytes) return fail(SG_ERR_STATE, "sg_jbu_upsample: workspace %zu < required %zu", ws_bytes, need);
+// The four 2x stages (JBULearnedRange.forward x 4): source [B, gh*gw, C] -> *x_out [B, 16gh*16gw, C] f32 inside the workspace
+// (and its bf16 copy in p.x16 in throughput mode when C % 64 == 0)
+static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
+                      const JbuPlan& p, const float** x_out, hipStream_t s) {
   const int C = j->C;
   const float* src = source;
   int h = gh, w = gw;
+  // low-res adaptive convolution (throughput mode): its bf16 stage outputs live in the region the hi-res tensor would have used
+  const bool lowres_ok = precision == SG_PREC_BF16 && C % 64 == 0 && gh >= 2 && gw >= 2;
+  bf16_t* tok16 = (bf16_t*)p.hr;
+  bf16_t* o16[3];
+  {
+    size_t off = align_up((size_t)B * gh * gw * C * 2, 256);
+    for (int t = 0; t < 3; ++t) { o16[t] = (bf16_t*)((char*)p.hr + off); off += align_up((size_t)B * (gh << (t + 1)) * (gw << (t + 1)) * C * 2, 256); }
+  }
   for (int stg = 0; stg < 4; ++stg) {
     const JbuStage& S = j->st[j->kind == 0 ? 0 : stg];
     const int r = S.r, d = 2 * r + 1, d2 = d * d, oh = 2 * h, ow = 2 * w;
@@ -615,6 +797,25 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
       SG_TRY(gemm_f32(q, s));
     }
     const bool mfma_conv = fast;
+    const bool lowres = fast && (r == 5 || r == 3) && lowres_ok;   // bicubic folded into the per-pixel kernel: no hi-res tensor at all
+    if (lowres) {
+      // bf16 chain: tokens -> o16[0] (2x) -> o16[1] (4x) -> o16[2] (8x) -> x16 (16x); f32 only out of the last stage
+      bf16_t* s16 = stg == 0 ? tok16 : o16[stg - 1];
+      if (stg == 0) SG_TRY(pack_rows(source, (int64_t)B * gh * gw, C, C, tok16, C, 1, s));
+      bf16_t* d16 = stg == 3 ? (bf16_t*)p.x16 : o16[stg];
+      float* d32 = stg == 3 ? dst : nullptr;
+      dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
+      if (r == 5) {
+        SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_kernel<5>), LowCfg<5>::LDS));
+        hipLaunchKernelGGL(jbu_conv_lowres_kernel<5>, grid, dim3(256), LowCfg<5>::LDS, s, s16, p.Kf, ldk, h, w, C, d32, d16);
+      } else {
+        SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_kernel<3>), LowCfg<3>::LDS));
+        hipLaunchKernelGGL(jbu_conv_lowres_kernel<3>, grid, dim3(256), LowCfg<3>::LDS, s, s16, p.Kf, ldk, h, w, C, d32, d16);
+      }
+      SG_LAUNCH_CHECK();
+      src = dst; h = oh; w = ow;
+      continue;
+    }
     if (mfma_conv) hipLaunchKernelGGL(jbu_bicubic_kernel<bf16_t>, dim3((unsigned)cdiv(pixels * (C / 4), 256)), dim3(256), 0, s, src, B, h, w, C, oh, ow, (bf16_t*)p.hr);
     else hipLaunchKernelGGL(jbu_bicubic_kernel<float>, dim3((unsigned)cdiv(pixels * (C / 4), 256)), dim3(256), 0, s, src, B, h, w, C, oh, ow, p.hr);
     SG_LAUNCH_CHECK();
@@ -637,8 +838,25 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
     }
     src = dst; h = oh; w = ow;
   }
+  *x_out = src;
+  return SG_OK;
+}
+
+// source [B, gh*gw, C] (patch tokens), guidance [B,3,GH,GW] (the normalised, padded tile) -> out [B, (16gh*16gw), C]
+extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
+                               float* out, void* ws, size_t ws_bytes, sg_stream st) {
+  SG_REQUIRE(j && source && guidance && out && ws, "sg_jbu_upsample: null argument");
+  for (size_t i = 0; i < j->have.size(); ++i) if (!j->have[i]) return fail(SG_ERR_STATE, "sg_jbu_upsample: upsampler weights incomplete");
+  DeviceGuard dg(j->device);
+  hipStream_t s = as_stream(st);
+  JbuPlan p;
+  const size_t need = jbu_plan(j, B, gh, gw, ws, false, p);
+  if (need > ws_bytes) return fail(SG_ERR_STATE, "sg_jbu_upsample: workspace %zu < required %zu", ws_bytes, need);
+  const int C = j->C;
+  const float* src = nullptr;
+  SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &src, s));
   // out = x + 0.1 * (x . Wf^T + bf)     (bias pre-scaled by 0.1 at load)
-  const int64_t pixels = (int64_t)B * h * w;
+  const int64_t pixels = (int64_t)B * 16 * gh * 16 * gw;
   if (precision == SG_PREC_BF16 && C % 64 == 0) {
     if (C % 8 != 0) SG_TRY(pack_rows(src, pixels, C, C, p.x16, C, 1, s));    // (C % 64 == 0 implies the matrix-core conv wrote x16 already)
     GemmBf16Args g{};
@@ -650,6 +868,134 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
   g.A = src; g.lda = C; g.B = j->fin_w; g.sbk = 1; g.sbn = C; g.bias = j->fin_b; g.residual = src; g.ldr = C; g.C = out; g.ldc = C;
   g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.inner = 1; g.act = 0; g.alpha = 0.1f;
   return gemm_f32(g, s);
+}
+
+// ---- fused tail (throughput mode): per-pixel class logits WITHOUT writing the C x S^2 feature map ---------------------------------
+// reference: out = x + 0.1 * fixup_proj(x) (upsamplers.py:301,325); feats /= |feats|; logits = feats . T^T (+ lambda * cls_logits)
+// (segmentor.py:374-379).  With z = 0.1 * (x Wf^T + bf):
+//     out . T[q]  = x . (T[q] + 0.1 Wf^T T[q]) + 0.1 bf . T[q]  =  x . Geff[:, q] + g0[q]          (f32, no GEMM: Q <= 32)
+//     |out|^2     = |x|^2 + sum_c z (2 x + z)                                                       (the GEMM's row-dot epilogue)
+// so the only C x C GEMM keeps its result in registers and HBM sees x once more (f32) plus Q floats per pixel.
+namespace sg {
+__global__ void jbu_geff_kernel(const float* __restrict__ text, const float* __restrict__ Wf, const float* __restrict__ bf01, int C, int Q,
+                                float* __restrict__ geff, float* __restrict__ g0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;            // (c, q)
+  if (i < C * Q) {
+    const int c = i / Q, q = i % Q;
+    float a = 0.f;
+    for (int k = 0; k < C; ++k) a += Wf[(int64_t)k * C + c] * text[(int64_t)q * C + k];   // (Wf^T T^T)[c, q]
+    geff[c * JBU_QMAX + q] = text[(int64_t)q * C + c] + 0.1f * a;
+  }
+  if (i < Q) {
+    float a = 0.f;
+    for (int k = 0; k < C; ++k) a += bf01[k] * text[(int64_t)i * C + k];                  // bf01 = 0.1 * bias (scaled at load)
+    g0[i] = a;
+  }
+}
+// cls_logits[b, q] = (cls[b] / |cls[b]|) . T[q]     (segmentor.py:309-311)
+__global__ __launch_bounds__(64) void jbu_cls_logits_kernel(const float* __restrict__ cls, const float* __restrict__ text, int C, int Q,
+                                                            float* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* cr = cls + (int64_t)b * C;
+  float ss = 0.f;
+  for (int i = lane; i < C; i += 64) ss += cr[i] * cr[i];
+  const float inv = 1.0f / sqrtf(wave_sum(ss));
+  for (int q = 0; q < Q; ++q) {
+    float d = 0.f;
+    for (int i = lane; i < C; i += 64) d += cr[i] * text[(int64_t)q * C + i];
+    d = wave_sum(d);
+    if (lane == 0) out[b * JBU_QMAX + q] = d * inv;
+  }
+}
+// 8 lanes per pixel: each lane owns C/8 channels (float4 strided by 8 lanes: 128 B contiguous per step), Q running dots + |x|^2 in
+// registers, 3 shuffle steps to combine; Geff lives in LDS (C x QP floats).
+template <int QP>
+__global__ __launch_bounds__(256) void jbu_pixel_logits_kernel(const float* __restrict__ x, const float* __restrict__ rowdot, int slots,
+                                                               const float* __restrict__ geff, const float* __restrict__ g0,
+                                                               const float* __restrict__ clsl, float lambda, int64_t pixels, int64_t P, int C,
+                                                               int Q, float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) float sG[];     // [C][QP], 4 pad floats after every 4 channels: the 8 lanes of a pixel
+  for (int i = threadIdx.x; i < C * QP; i += 256) {               // (channels 4 apart) read 8 different bank groups
+    const int c = i / QP, q = i % QP;
+    sG[c * QP + (c >> 2) * 4 + q] = q < Q ? geff[c * JBU_QMAX + q] : 0.f;
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 7;
+  const int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool live = pix < pixels;
+  const float* xr = x + (live ? pix : 0) * C;
+  float acc[QP], nx = 0.f;
+#pragma unroll
+  for (int q = 0; q < QP; ++q) acc[q] = 0.f;
+  for (int c = sub * 4; c < C; c += 32) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    nx += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    const float* g = sG + c * QP + c;                            // c is a multiple of 4: (c >> 2) * 4 == c
+#pragma unroll
+    for (int q = 0; q < QP; ++q) acc[q] += v.x * g[q] + v.y * g[QP + q] + v.z * g[2 * QP + q] + v.w * g[3 * QP + q];
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    nx += __shfl_xor(nx, o, 64);
+#pragma unroll
+    for (int q = 0; q < QP; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
+  }
+  if (!live) return;
+  float n2 = nx;
+  for (int sidx = 0; sidx < slots; ++sidx) n2 += rowdot[pix * slots + sidx];          // fixed order: deterministic
+  const float inv = 1.0f / sqrtf(n2);
+  const int64_t b = pix / P, pp = pix % P;
+#pragma unroll
+  for (int q = 0; q < QP; ++q)
+    if (q < Q && (q & 7) == sub) {
+      float v = (acc[q] + g0[q]) * inv;
+      if (clsl) v += lambda * clsl[b * JBU_QMAX + q];
+      logits[(b * Q + q) * P + pp] = v;
+    }
+}
+}  // namespace sg
+
+// sg_jbu_logits replaces, for a batch of tiles,  feats = upsampler(tokens, img) -> feats /= |feats| -> feats @ T^T (+ lambda * cls_logits)
+// (segmentor.py:368-379) without materialising the [S^2, C] feature map (throughput mode).
+extern "C" int sg_jbu_logits(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
+                             const float* text, int Q, const float* cls, float cls_token_lambda, float* logits, void* ws, size_t ws_bytes,
+                             sg_stream st) {
+  SG_REQUIRE(j && source && guidance && text && logits && ws, "sg_jbu_logits: null argument");
+  SG_REQUIRE(Q >= 1 && Q <= JBU_QMAX, "sg_jbu_logits: 1 <= Q <= %d", JBU_QMAX);
+  SG_REQUIRE(precision == SG_PREC_BF16 && j->C % 64 == 0 && j->C >= 512, "sg_jbu_logits: the fused tail is the bf16 throughput path (C %% 64 == 0, C >= 512); use sg_jbu_upsample + sg_cosine_logits otherwise");
+  for (size_t i = 0; i < j->have.size(); ++i) if (!j->have[i]) return fail(SG_ERR_STATE, "sg_jbu_logits: upsampler weights incomplete");
+  DeviceGuard dg(j->device);
+  hipStream_t s = as_stream(st);
+  JbuPlan p;
+  const size_t need = jbu_plan(j, B, gh, gw, ws, false, p);
+  if (need > ws_bytes) return fail(SG_ERR_STATE, "sg_jbu_logits: workspace %zu < required %zu", ws_bytes, need);
+  const int C = j->C;
+  const int64_t P = (int64_t)16 * gh * 16 * gw, pixels = (int64_t)B * P;
+  SG_REQUIRE(pixels >= 1024 && pixels < (1ll << 31), "sg_jbu_logits: pixel count out of range");
+  const float* x = nullptr;
+  SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &x, s));
+  hipLaunchKernelGGL(jbu_geff_kernel, dim3((unsigned)cdiv((int64_t)C * Q, 256)), dim3(256), 0, s, text, j->fin_w, j->fin_b, C, Q, p.geff, p.g0);
+  SG_LAUNCH_CHECK();
+  const bool use_cls = cls != nullptr && cls_token_lambda != 0.f;
+  if (use_cls) { hipLaunchKernelGGL(jbu_cls_logits_kernel, dim3(B), dim3(64), 0, s, cls, text, C, Q, p.clsl); SG_LAUNCH_CHECK(); }
+  GemmBf16Args g{};
+  g.A = (const bf16_t*)p.x16; g.lda = C; g.W = (const bf16_t*)j->fin_w16; g.ldw = C; g.bias = j->fin_b; g.residual = x; g.ldr = C;
+  g.C = p.rowdot; g.ldc = C; g.c_is_bf16 = 0; g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.act = 0; g.alpha = 0.1f;
+  g.rowdot = p.rowdot; g.rowdot_ld = C / 64;
+  SG_TRY(gemm_bf16(g, s));
+  const int slots = C / 64;
+  const unsigned grid = (unsigned)cdiv(pixels, 32);
+#define SG_JBU_PIX(QP)                                                                                                        \
+  do {                                                                                                                         \
+    const size_t lds = (size_t)(C * QP + C) * sizeof(float);                                                                   \
+    if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_pixel_logits_kernel<QP>), lds));         \
+    hipLaunchKernelGGL(jbu_pixel_logits_kernel<QP>, dim3(grid), dim3(256), lds, s, x, p.rowdot, slots, p.geff, p.g0,           \
+                       use_cls ? p.clsl : nullptr, cls_token_lambda, pixels, P, C, Q, logits);                                 \
+  } while (0)
+  if (Q <= 8) SG_JBU_PIX(8); else if (Q <= 16) SG_JBU_PIX(16); else SG_JBU_PIX(32);
+#undef SG_JBU_PIX
+  SG_LAUNCH_CHECK();
+  return SG_OK;
 }
 
 extern "C" int sg_extract_tiles(const sg_tile_batch* t, int up_h, int up_w, float* out, sg_stream s) {

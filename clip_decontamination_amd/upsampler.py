@@ -37,6 +37,7 @@ class HipJBU:
         self._ctx = C.c_void_p()
         self._ws = {}
         self.tiles_per_launch = 8            # tiles per JBU launch (workspace ~2.2 GB per 512-pixel tile)
+        self.fused_tail = True               # bf16 mode: sg_jbu_logits (no [S^2, C] feature map); False = upsample + cosine_logits
         with torch.cuda.device(self.device):
             check(self.lib.sg_jbu_create(C.byref(self._ctx), self.device.index or 0, KINDS[model_name], feat_dim), "sg_jbu_create")
 
@@ -135,7 +136,18 @@ class HipJBU:
                 tb.n_tiles, tb.tile_h, tb.tile_w, tb.pad_l, tb.pad_t, tb.grid_h, tb.grid_w = c, th, tw, l, t, gh, gw
                 guid = torch.empty(c, 3, ph, pw, dtype=torch.float32, device=self.device)
                 check(self.lib.sg_extract_tiles(C.byref(tb), ph, pw, ptr(guid), stream_ptr(self.device)), "sg_extract_tiles")
-                feats = self.upsample_tokens(tokens[i:i + c], guid, gh, gw)                      # [c, 256 n, C]
-                lg = ops.cosine_logits(feats, None if cls is None else cls[i:i + c], text, 0.0, cls_token_lambda if cls is not None else 0.0)
+                lam = float(cls_token_lambda) if cls is not None else 0.0
+                if self.fused_tail and self.precision == _lib.PREC_BF16 and self.feat_dim % 64 == 0 and self.feat_dim >= 512 and Q <= 32:
+                    # throughput mode: JBU + L2-norm + x T^T in one call; the [S^2, C] feature map never reaches HBM
+                    lg = torch.empty(c, Q, 256 * gh * gw, dtype=torch.float32, device=self.device)
+                    tk = tokens[i:i + c].contiguous().float()
+                    ci = None if (cls is None or lam == 0.0) else cls[i:i + c].contiguous().float()
+                    need = self.lib.sg_jbu_workspace_bytes(self._ctx, c, gh, gw)
+                    wp, wn = self._workspace(need)
+                    check(self.lib.sg_jbu_logits(self._ctx, ptr(tk), ptr(guid), c, gh, gw, ph, pw, self.precision, ptr(text), Q, ptr(ci), lam,
+                                                 ptr(lg), wp, wn, stream_ptr(self.device)), "sg_jbu_logits")
+                else:
+                    feats = self.upsample_tokens(tokens[i:i + c], guid, gh, gw)                      # [c, 256 n, C]
+                    lg = ops.cosine_logits(feats, None if cls is None else cls[i:i + c], text, 0.0, lam)
                 outs.append(lg.reshape(c, Q, 16 * gh, 16 * gw))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]

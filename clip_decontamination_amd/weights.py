@@ -60,6 +60,8 @@ VIT_CONFIGS: Dict[str, VitConfig] = {
     "tiny-16": VitConfig("tiny-16", 128, 5, 2, 16, 64, image_size=64),
     "tiny-gem": VitConfig("tiny-gem", 64, 8, 2, 8, 32, image_size=32),     # >= 7 layers for GEM depth 7
     "tiny-gelu": VitConfig("tiny-gelu", 64, 4, 2, 8, 32, image_size=32, quick_gelu=False),
+    # ONE head: the only head count at which the reference's apply_layer_fusion + outlier suppressor path runs (R9) -- pins its semantics
+    "tiny-1h": VitConfig("tiny-1h", 64, 4, 1, 8, 32, image_size=32),
 }
 
 

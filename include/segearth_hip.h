@@ -269,6 +269,16 @@ size_t sg_jbu_workspace_bytes(const sg_jbu* j, int B, int gh, int gw);
 int  sg_jbu_upsample(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
                      float* out, void* workspace, size_t workspace_bytes, sg_stream s);
 
+/* sg_jbu_logits (throughput mode, bf16, C % 64 == 0) replaces segmentor.py:368-379 for a batch of tiles in one call:
+ *   feats = upsampler(tokens -> [1,C,g,g], img); feats /= |feats|; logits = feats @ T^T (+ cls_token_lambda * cls_logits)
+ * with the JBU tail fused: out = x + 0.1 * fixup_proj(x) is never written -- the C x C 1x1 conv (upsamplers.py:301,325) runs as a GEMM whose
+ * epilogue only accumulates |out|^2 per pixel, and out . T^T = x . (T^T + 0.1 Wf^T T^T) + 0.1 bf . T^T is a Q-wide f32 product.
+ *   source [B, gh*gw, C] (global debias already applied), guidance [B,3,GH,GW], text [Q,C] (Q <= 32), cls [B,C] or NULL
+ *   -> logits [B, Q, 16gh*16gw] f32.  Workspace as sg_jbu_workspace_bytes. */
+int  sg_jbu_logits(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
+                   const float* text, int Q, const float* cls, float cls_token_lambda, float* logits, void* workspace, size_t workspace_bytes,
+                   sg_stream s);
+
 /* the normalised, zero-padded tile planes [T,3,up_h,up_w] f32 the reference hands to the upsampler as `img`
  * (segmentor.py:424-431 crop + pad, :371) */
 int sg_extract_tiles(const sg_tile_batch* tiles, int up_h, int up_w, float* out, sg_stream s);

@@ -3,7 +3,7 @@
 deterministic synthetic weights and inputs.  Runs only in the build container; the fixtures are
 data (inputs' seeds + expected outputs), never reference source.
 
-    python -m oracle.gen_golden [--only tiny|refine|jbu|jbu_real|segment|text|ctd|real]
+    python -m oracle.gen_golden [--only tiny|layer_fusion|refine|jbu|jbu_real|segment|text|ctd|real]
 
 Every fixture is cross-checked here against the build's own CPU restatement (oracle/*.py) so a
 drift between the two fails at mint time, and again in tests/test_oracle_vs_golden.py.
@@ -199,6 +199,56 @@ def gen_tiny():
                 out[f"{nm}.ign{int(ign)}.tokens"] = tok
                 out[f"{nm}.img"] = im
     save("vit_tiny-gem", **out)
+
+
+def gen_layer_fusion():
+    """apply_layer_fusion (transformer.py:598-607,630-637,647-690).  With an outlier suppressor installed the reference's
+    ``attn_accumulated.view(N, num_heads, L, L)`` only works when heads == 1 (the attention it accumulates is already head-averaged,
+    R9): a ONE-head tiny tower pins the semantics; without a suppressor the fusion is a no-op on any head count (pinned on tiny-8)."""
+    print("[layer_fusion] reference apply_layer_fusion=True")
+    out = {}
+    with torch.no_grad():
+        cfg = Wt.vit_config("tiny-1h")
+        wnp = Wt.make_vit_weights(cfg, seed=0)
+        w = OV.to_torch(wnp)
+        net = ref_clip(cfg, wnp)
+        img = rand_img(31, 2, 48, 48)
+        out["img"] = img
+        sim_cfg = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
+        for tag, sc, lam, ign in (("lf", None, 0.5, True), ("lf_sim", sim_cfg, 0.3, True), ("lf_res", None, 0.5, False)):
+            for mt in ("SegEarth", "Experimental"):
+                install_refiners(net, sc, dict(top_k=5), None)
+                cls, tok = net.encode_image(img, mt, ign, output_cls_token=True, apply_layer_fusion=True, layer_fusion_lambda=lam,
+                                            apply_similarity_enhancement=sc is not None)
+                cap = {}
+                ocls, otok = OV.vit_forward(w, cfg, img, mt, ign, similarity_cfg=sc, outlier_cfg=dict(top_k=5), layer_fusion={"lambda": lam},
+                                            capture=cap)
+                close(otok, tok, 3e-5, f"tiny-1h {tag}/{mt} tokens")
+                close(ocls, cls, 3e-5, f"tiny-1h {tag}/{mt} cls")
+                out[f"{tag}.{mt}.cls"], out[f"{tag}.{mt}.tokens"] = cls, tok
+                if tag == "lf" and mt == "SegEarth":
+                    out["inter.fused_attn"] = cap["fused_attn"]
+                    out["inter.fusion_idx"] = cap["fusion_idx"]
+        install_refiners(net)
+        # no suppressor: fusion computed and discarded (any head count)
+        cfg8 = Wt.vit_config("tiny-8")
+        wnp8 = Wt.make_vit_weights(cfg8, seed=0)
+        net8 = ref_clip(cfg8, wnp8)
+        install_refiners(net8)
+        cls, tok = net8.encode_image(img, "SegEarth", True, output_cls_token=True, apply_layer_fusion=True)
+        cls0, tok0 = net8.encode_image(img, "SegEarth", True, output_cls_token=True)
+        close(tok, tok0, 1e-5, "tiny-8 fusion without suppressor == no fusion (need_weights=True takes the unfused MHA path: rounding only)")
+        ocls, otok = OV.vit_forward(OV.to_torch(wnp8), cfg8, img, "SegEarth", True, layer_fusion={"lambda": 0.5})
+        close(otok, tok, 3e-5, "tiny-8 noop tokens")
+        out["noop8.tokens"] = tok
+        # heads > 1 with a suppressor: the reference raises (recorded, not a fixture)
+        install_refiners(net8, None, dict(top_k=5), None)
+        try:
+            net8.encode_image(img, "SegEarth", True, output_cls_token=True, apply_layer_fusion=True)
+            print("    reference with heads=2 + suppressor: ran (unexpected)")
+        except RuntimeError as e:
+            print(f"    reference with heads=2 + suppressor raises, as SURVEY R9 says: {str(e)[:90]}")
+    save("vit_tiny-1h", **out)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -509,7 +559,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    steps = {"tiny": gen_tiny, "refine": gen_refine, "jbu": gen_jbu, "jbu_real": gen_jbu_real, "segment": gen_segment, "text": gen_text, "ctd": gen_ctd, "real": gen_real}
+    steps = {"tiny": gen_tiny, "layer_fusion": gen_layer_fusion, "refine": gen_refine, "jbu": gen_jbu, "jbu_real": gen_jbu_real, "segment": gen_segment, "text": gen_text, "ctd": gen_ctd, "real": gen_real}
     for k, fn in steps.items():
         if not a.only or a.only == k:
             fn()

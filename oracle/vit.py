@@ -179,9 +179,19 @@ def last_block_attention(w: W, cfg, i: int, xn, model_type: str, sim_bias=None, 
 
 def vit_forward(w: W, cfg, img, model_type: str = "SegEarth", ignore_residual: bool = True,
                 similarity_cfg: Optional[dict] = None, outlier_cfg: Optional[dict] = None,
-                self_attn_cfg: Optional[dict] = None, capture: Optional[dict] = None):
-    """open_clip/transformer.py:538-775 with ``last_n_layers=1``, ``output_cls_token=True``,
-    layer fusion off.  Returns (cls [B,E], tokens [B,n,E]).
+                self_attn_cfg: Optional[dict] = None, capture: Optional[dict] = None, layer_fusion: Optional[dict] = None):
+    """open_clip/transformer.py:538-775 with ``last_n_layers=1``, ``output_cls_token=True``.
+    Returns (cls [B,E], tokens [B,n,E]).
+
+    ``layer_fusion``: None = ``apply_layer_fusion=False``; else ``{"lambda": l}`` = the reference's attention-map fusion
+    (transformer.py:598-607, 630-637, 647-690) with its view(N, heads, L, L) read as what it can only mean: the attention of
+    ``blk(x, need_weights=True)`` is ALREADY head-averaged [B,L,L] (nn.MultiheadAttention default), so the fused map is used as is.
+    The reference reaches that reading exactly when heads == 1 (fixture vit_tiny-1h); for heads > 1 its view() raises (R9).
+      * every ordinary block (and, with ignore_residual, the last block's own ``blk(x)``) contributes A_l; acc = l*acc + (1-l)*A_l;
+      * the capture of block L-2's attention for the refiners is NOT taken (the ``elif`` at :609), so the self-attention enhancer and
+        the outlier SUPPRESSION are skipped; with an outlier suppressor installed its top_k selects columns of the fused map to
+        zero, rows are L1-renormalised (+1e-8) and ``output = attn @ output`` (all N tokens, CLS included); without one the fused
+        map is discarded (the forward equals the unfused one).  ``layer_fusion_threshold`` is unused by the reference.
 
     ``similarity_cfg`` / ``outlier_cfg`` / ``self_attn_cfg``: None = module not installed,
     else the kwargs of the corresponding reference module.
@@ -190,13 +200,16 @@ def vit_forward(w: W, cfg, img, model_type: str = "SegEarth", ignore_residual: b
     L = cfg.layers
     x, gh, gw = embed(w, cfg, img)
     mid_idx = (L - 1) // 2                                     # transformer.py:593
-    want_attn = outlier_cfg is not None                        # transformer.py:609 (R6)
-    x_mid, attn = None, None
+    want_attn = outlier_cfg is not None and layer_fusion is None   # transformer.py:609 (R6); :598 takes precedence over the elif
+    lam = None if layer_fusion is None else float(layer_fusion.get("lambda", 0.5))
+    x_mid, attn, acc = None, None, None
     for i in range(L - 1):
         if i == mid_idx and similarity_cfg is not None:
             x_mid = x.clone()
-        x, a = res_block(w, cfg, i, x, need_weights=(want_attn and i == L - 2))
-        if a is not None:
+        x, a = res_block(w, cfg, i, x, need_weights=(lam is not None) or (want_attn and i == L - 2))
+        if lam is not None:
+            acc = a if acc is None else lam * acc + (1.0 - lam) * a       # transformer.py:601-607
+        elif a is not None:
             attn = a
     sim = None
     sim_weight = 1.0
@@ -209,9 +222,22 @@ def vit_forward(w: W, cfg, img, model_type: str = "SegEarth", ignore_residual: b
     if not ignore_residual:                                    # transformer.py:641-643
         out = x + out
         out = out + mlp(w, p, layer_norm(out, w, p + "ln_2"), cfg.quick_gelu)
+    if lam is not None and ignore_residual:                    # transformer.py:630-637: the last block's ordinary attention joins the EMA
+        _, a = res_block(w, cfg, L - 1, x, need_weights=True)
+        acc = a if acc is None else lam * acc + (1.0 - lam) * a
     if capture is not None:
-        capture.update(x_pre_last=x, x_mid=x_mid, attn=attn, sim=sim, last_out=out.clone(), gh=gh, gw=gw)
+        capture.update(x_pre_last=x, x_mid=x_mid, attn=attn, sim=sim, last_out=out.clone(), gh=gh, gw=gw, fused_attn=acc)
     B, N, D = out.shape
+    if lam is not None and acc is not None and outlier_cfg is not None:       # transformer.py:647-690
+        idx = refine.detect_outliers(acc, gh * gw, outlier_cfg.get("top_k", 10))
+        mask = torch.ones(B, N)
+        for b in range(B):
+            mask[b, idx[b] + 1] = 0.0
+        am = acc * mask.unsqueeze(1)
+        am = am / (am.sum(dim=-1, keepdim=True) + 1e-8)
+        out = torch.bmm(am, out)
+        if capture is not None:
+            capture.update(fusion_idx=idx)
     if attn is not None and self_attn_cfg is not None:         # transformer.py:698-718
         grid = out[:, 1:].permute(0, 2, 1).reshape(B, D, gh, gw)
         grid = refine.self_attention_enhance(grid, attn, **self_attn_cfg)

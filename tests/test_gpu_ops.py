@@ -313,6 +313,71 @@ def test_jbu_on_the_trained_checkpoint(golden, precision):
     assert err < tol and err_sq < tol, (err, err_sq)
 
 
+@pytest.mark.parametrize("name,C,gh,gw", [("jbu_one", 64, 4, 4), ("jbu_one", 128, 3, 5), ("jbu_stack", 64, 5, 3), ("jbu_one", 64, 9, 10)])
+def test_jbu_throughput_mode_lowres_conv_vs_oracle(name, C, gh, gw):
+    """bf16 throughput mode (C % 64 == 0): the adaptive convolution runs on the LOW-RES source with the bicubic 2x folded into the
+    per-pixel kernel (Keff = Wy^T K Wx, jbu_conv_lowres_kernel, radius 5 and 3); borders, ragged last blocks (sizes that are not
+    multiples of 8) and batches against the fp32 oracle.  bf16 rounds features and kernel weights: ~5e-3 relative measured."""
+    from clip_decontamination_amd import weights as Wt
+    from clip_decontamination_amd.upsampler import get_upsampler
+    from oracle import vit as OV
+    wnp = Wt.make_jbu_weights(name, C, seed=3)
+    src = rnd(2, C, gh, gw, seed=1)
+    guid = torch.nn.functional.interpolate(rnd(2, 3, 5, 7, seed=2), size=(16 * gh, 16 * gw), mode="bicubic") + 0.2 * rnd(2, 3, 16 * gh, 16 * gw, seed=3)
+    ref = torch.cat([OJ.jbu_forward(OV.to_torch(wnp), src[i:i + 1], guid[i:i + 1]) for i in range(2)], 0)
+    up = get_upsampler(name, C, DEV, "bf16")
+    up.load_state_dict(wnp)
+    out = up(src.to(DEV), guid.to(DEV)).cpu()
+    rel = (out - ref).abs().max().item() / ref.abs().max().item()
+    print(f"low-res conv [{name} C={C} {gh}x{gw}]: max rel err {rel:.3e}")
+    assert rel < 1.5e-2, rel
+
+
+@pytest.mark.parametrize("use_cls", [False, True])
+def test_jbu_fused_logits_tail_equals_unfused_and_oracle(golden, ops, use_cls):
+    """sg_jbu_logits (bf16 throughput mode: row-dot GEMM epilogue + Q-wide f32 product, the [S^2, C] map never written) against
+    (a) the unfused bf16 path (sg_jbu_upsample -> sg_cosine_logits) and (b) the fp32 oracle, on the reference's trained JBUStack(512)."""
+    import ctypes as C
+    from clip_decontamination_amd import _lib
+    from clip_decontamination_amd.upsampler import get_upsampler
+    from clip_decontamination_amd.ops import ptr, stream_ptr
+    g = golden("jbu_real")
+    w = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")}
+    up = get_upsampler("jbu_stack", 512, DEV, "bf16")
+    up.load_state_dict(w)
+    B, Q, gs = 2, 15, 4
+    src = torch.cat([torch.from_numpy(g["src"]), rnd(1, 512, gs, gs, seed=5)], 0)
+    guid = torch.cat([torch.from_numpy(g["guidance"]), torch.from_numpy(g["guidance"]).flip(-1) * 0.7], 0)
+    text = torch.nn.functional.normalize(rnd(Q, 512, seed=8), dim=-1)
+    cls = rnd(B, 512, seed=9) if use_cls else None
+    lam = -0.3 if use_cls else 0.0
+    tok = src.permute(0, 2, 3, 1).reshape(B, gs * gs, 512).contiguous().to(DEV)
+    feats = up.upsample_tokens(tok, guid.to(DEV), gs, gs)
+    unfused = ops.cosine_logits(feats, None if cls is None else cls.to(DEV), text.to(DEV), 0.0, lam)            # [B,Q,P]
+    lib = _lib.load()
+    P = 256 * gs * gs
+    fused = torch.empty(B, Q, P, dtype=torch.float32, device=DEV)
+    need = lib.sg_jbu_workspace_bytes(up._ctx, B, gs, gs)
+    wp, wn = up._workspace(need)
+    gd, td = guid.to(DEV).contiguous(), text.to(DEV).contiguous()
+    cd = None if cls is None else cls.to(DEV).contiguous()
+    _lib.check(lib.sg_jbu_logits(up._ctx, ptr(tok), ptr(gd), B, gs, gs, 16 * gs, 16 * gs, _lib.PREC_BF16, ptr(td), Q, ptr(cd), lam, ptr(fused), wp, wn,
+                                 stream_ptr()), "sg_jbu_logits")
+    d_fu = (fused - unfused).abs().max().item()
+    with torch.no_grad():
+        o = torch.cat([OJ.jbu_forward(w, src[i:i + 1], guid[i:i + 1]) for i in range(B)], 0)                  # [B,C,S,S]
+        f = o.reshape(B, 512, P).permute(0, 2, 1)
+        ref = (f / f.norm(dim=-1, keepdim=True)) @ text.T
+        if use_cls:
+            cn = cls / cls.norm(dim=-1, keepdim=True)
+            ref = ref + lam * (cn @ text.T).unsqueeze(1)
+        ref = ref.permute(0, 2, 1)
+    d_or = (fused.cpu() - ref).abs().max().item()
+    d_un = (unfused.cpu() - ref).abs().max().item()
+    print(f"fused JBU tail (cls={use_cls}): |fused - unfused| = {d_fu:.3e}; vs fp32 oracle: fused {d_or:.3e}, unfused {d_un:.3e}")
+    assert d_fu < 2e-3 and d_or < 3e-3
+
+
 def test_jbu_against_oracle_nonsquare_and_batched():
     from clip_decontamination_amd import weights as Wt
     from clip_decontamination_amd.upsampler import get_upsampler
