@@ -28,7 +28,8 @@ class ForwardOpts(C.Structure):
                 ("similarity_weight", C.c_float), ("similarity_temperature", C.c_float), ("similarity_add_self", C.c_int32),
                 ("outlier_enabled", C.c_int32), ("outlier_top_k", C.c_int32), ("outlier_contamination_temp", C.c_float),
                 ("selfattn_enabled", C.c_int32), ("selfattn_mode", C.c_int32), ("selfattn_top_k", C.c_int32),
-                ("selfattn_strength", C.c_float), ("selfattn_threshold", C.c_float), ("gem_depth", C.c_int32)]
+                ("selfattn_strength", C.c_float), ("selfattn_threshold", C.c_float), ("gem_depth", C.c_int32),
+                ("layer_fusion_enabled", C.c_int32), ("layer_fusion_lambda", C.c_float)]
 
 
 class TileBatch(C.Structure):

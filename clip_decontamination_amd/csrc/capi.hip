@@ -291,7 +291,8 @@ struct Plan {
   float *scores, *probs;
   float *omega, *qnorm, *knorm;
   uint8_t *x8, *h8; float *sx8, *sh8;                     // SG_PREC_FP8: quantised LN output / GELU output + per-row scales
-  float *attn_avg, *sa_tmp, *sa_qk32, *sa_scores, *sa_probs;   // self-attention enhancement, mode='attention'
+  float *attn_avg, *sa_tmp, *sa_qk32, *sa_scores, *sa_probs;   // self-attention enhancement, mode='attention'; layer fusion
+  float *lf_acc;                                              // layer fusion: the EMA of the head-averaged attention maps [B,N,N]
   // GEM
   float* x_gem; void* gnorm[3]; void* gatt[3]; float* inv_temp; float* gem_out; void* ctx2;
 };
@@ -331,8 +332,9 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.refine_scratch = b.take(refine_scratch_bytes(B, d.width, kmax > 0 ? kmax : 1));
   p.scores = p.probs = nullptr;
   if (!c->hk) { p.scores = b.get<float>((size_t)B * d.heads * N * N); p.probs = b.get<float>((size_t)B * d.heads * N * N); }
-  p.attn_avg = p.sa_tmp = p.sa_qk32 = p.sa_scores = p.sa_probs = nullptr;
-  if (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1) {
+  p.attn_avg = p.sa_tmp = p.sa_qk32 = p.sa_scores = p.sa_probs = p.lf_acc = nullptr;
+  if (o->layer_fusion_enabled) p.lf_acc = b.get<float>((size_t)B * N * N);
+  if (o->layer_fusion_enabled || (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1)) {
     p.attn_avg = b.get<float>((size_t)B * N * N); p.sa_tmp = b.get<float>(R * d.width);
     if (c->hk) {                                        // one image at a time: f32 copies of q|k, scores and probabilities of all heads
       p.sa_qk32 = b.get<float>((size_t)N * 2 * d.width); p.sa_scores = b.get<float>((size_t)d.heads * N * N); p.sa_probs = b.get<float>((size_t)d.heads * N * N);
@@ -672,12 +674,19 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     SG_TRY(layernorm(p.x_gem, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->hk, R, D, 1e-5f, s));
   } else {
     const int mid = (L - 1) / 2;                                      // transformer.py:593
-    const bool want_stats = o->outlier_enabled != 0;                  // transformer.py:609 (R6)
+    const bool fusion = o->layer_fusion_enabled != 0;                 // transformer.py:598: takes precedence over the elif at :609
+    const bool want_stats = o->outlier_enabled != 0 && !fusion;       // transformer.py:609 (R6)
+    const float lf = o->layer_fusion_lambda;
+    const int64_t BNN = (int64_t)B * N * N;
     for (int i = 0; i < L - 1; ++i) {
       if (i == mid && o->similarity_enabled)                          // normalised mid-layer patches (similarity_enhancement.py:49)
         SG_TRY(l2norm_rows(p.x + D, 0, (int64_t)N * D, D, n, p.xhat, c->hk, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));
       SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, want_stats && i == L - 2, s,
-                       want_stats && i == L - 2 && o->selfattn_enabled && o->selfattn_mode == 1));
+                       fusion || (want_stats && i == L - 2 && o->selfattn_enabled && o->selfattn_mode == 1)));
+      if (fusion) {                                                   // A_acc = lambda * A_acc + (1 - lambda) * A_l   (:601-607)
+        if (i == 0) SG_HIP(hipMemcpyAsync(p.lf_acc, p.attn_avg, (size_t)BNN * 4, hipMemcpyDeviceToDevice, s));
+        else SG_TRY(axpby(p.lf_acc, p.attn_avg, 1.0f - lf, lf, BNN, s));
+      }
     }
     if (o->similarity_enabled)
       SG_TRY(similarity_from_xhat(c->hk, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s, c->hk != HK_F32));
@@ -686,21 +695,43 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1, p.omega, p.qnorm, p.knorm};
     SG_TRY(layernorm(p.x, D, LL.ln1_g, LL.ln1_b, p.xn, D, c->hk, R, D, 1e-5f, s));
     SG_TRY(linear(c->hk, p.xn, D, LL.w_qkv, LL.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+    if (fusion && o->ignore_residual) {                               // :630-637: the last block's own blk(x) attention joins the EMA
+      if (!c->hk) {                                                   // parity mode: materialise the ordinary attention's probabilities
+        AttnBuffers av{p.scores, p.probs, p.lse, p.lse1, p.omega, p.qnorm, p.knorm};
+        SG_TRY(run_attention(c->hk, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, false, av, s));
+      }
+      SG_TRY(averaged_attention(c, p, B, N, s));
+      if (L == 1) SG_HIP(hipMemcpyAsync(p.lf_acc, p.attn_avg, (size_t)BNN * 4, hipMemcpyDeviceToDevice, s));
+      else SG_TRY(axpby(p.lf_acc, p.attn_avg, 1.0f - lf, lf, BNN, s));
+    }
     const void* ctx = p.ctx; int64_t ctx_ld = D;
     if (o->model_type == SG_MASKCLIP) { ctx = (const char*)p.qkv + (size_t)2 * D * c->esz; ctx_ld = 3 * D; }   // identity attention: ctx = v
     else SG_TRY(run_attention(c->hk, p.qkv, B, N, D, H, o->model_type, (o->similarity_enabled && o->model_type < SG_NACLIP) ? p.sim : nullptr, o->similarity_weight,
                               nullptr, p.ctx, false, ab, s, false, c->hk));
     SG_TRY(linear(c->hk, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
     if (!o->ignore_residual) SG_TRY(mlp_block(c, LL, p.out_last, p, R, s));
-    // ---- refinements on the last-block output (transformer.py:698-742) ----
-    if (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1) {
+    // ---- attention-map layer fusion: mask the fused map's outlier columns, renormalise, re-weight every token (transformer.py:647-690) ----
+    if (fusion && o->outlier_enabled) {
+      const int k = o->outlier_top_k < n ? o->outlier_top_k : n;
+      SG_TRY(fusion_row_diag(p.lf_acc, B, N, p.attn_cls, p.attn_diag, s));
+      SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 0, p.idx_out, s));
+      SG_TRY(fusion_mask_normalize(p.lf_acc, p.idx_out, B, N, k, s));
+      GemmF32Args g{};
+      g.A = p.lf_acc; g.lda = N; g.sAo = (int64_t)N * N; g.B = p.out_last; g.sbk = D; g.sbn = 1; g.sBo = (int64_t)N * D;
+      g.C = p.sa_tmp; g.ldc = D; g.sCo = (int64_t)N * D; g.M = N; g.N = D; g.K = N; g.batch = B; g.inner = 1; g.act = 0; g.alpha = 1.f;
+      SG_TRY(gemm_f32(g, s));
+      SG_HIP(hipMemcpyAsync(p.out_last, p.sa_tmp, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
+    }
+    // ---- refinements on the last-block output (transformer.py:698-742); need block L-2's attention, which layer fusion does not capture ----
+    if (fusion) {
+    } else if (o->outlier_enabled && o->selfattn_enabled && o->selfattn_mode == 1) {
       SG_TRY(attn_mode_enhance(p.out_last, (int64_t)N * D, D, p.attn_avg, B, N, D, o->selfattn_strength, o->selfattn_threshold, p.sa_tmp, s));
     } else if (o->outlier_enabled && o->selfattn_enabled) {
       const int k = o->selfattn_top_k < n ? o->selfattn_top_k : n;
       SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 1, p.idx_sa, s));
       SG_TRY(neighbour_refine(p.out_last, (int64_t)N * D, D, p.idx_sa, B, gh, gw, D, k, 0, 0.f, p.refine_scratch, s));
     }
-    if (o->outlier_enabled) {
+    if (o->outlier_enabled && !fusion) {
       const int k = o->outlier_top_k < n ? o->outlier_top_k : n;
       SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 0, p.idx_out, s));
       SG_TRY(neighbour_refine(p.out_last, (int64_t)N * D, D, p.idx_out, B, gh, gw, D, k, 1, o->outlier_contamination_temp, p.refine_scratch, s));

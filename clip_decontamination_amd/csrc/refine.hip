@@ -197,6 +197,46 @@ __global__ __launch_bounds__(256) void attn_boost_kernel(float* __restrict__ A, 
   const float inv = 1.0f / (wave_sum(sum) + 1e-8f);
   for (int j = lane; j < N; j += 64) r[j] = j == 0 ? 0.f : (r[j] + (j == i ? boost : 0.f)) * inv;
 }
+// ---- attention-map layer fusion (reference open_clip/transformer.py:647-690) ------------------------------------------------------
+// row 0 and the diagonal of the fused map [B,N,N] (what detect_outliers_by_attention consumes)
+__global__ void fusion_row_diag_kernel(const float* __restrict__ A, int N, float* __restrict__ a_cls, float* __restrict__ a_diag) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const float* Ab = A + (int64_t)b * N * N;
+  a_cls[(int64_t)b * N + j] = Ab[j];
+  a_diag[(int64_t)b * N + j] = Ab[(int64_t)j * (N + 1)];
+}
+// zero the columns 1 + idx[b, :] of A[b], then L1-normalise every row: A / (sum + 1e-8)   (:668-675); one wave per row, in place
+__global__ __launch_bounds__(256) void fusion_mask_normalize_kernel(float* __restrict__ A, const int32_t* __restrict__ idx, int N, int k) {
+  extern __shared__ int32_t s_idx[];
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < k; i += 256) s_idx[i] = idx[(int64_t)b * k + i] + 1;
+  __syncthreads();
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float* r = A + ((int64_t)b * N + row) * N;
+  float sum = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    bool masked = false;
+    for (int i = 0; i < k; ++i) masked = masked || (s_idx[i] == j);
+    const float v = masked ? 0.f : r[j];
+    r[j] = v;
+    sum += v;
+  }
+  const float inv = 1.0f / (wave_sum(sum) + 1e-8f);
+  for (int j = lane; j < N; j += 64) r[j] *= inv;
+}
+int fusion_row_diag(const float* A, int B, int N, float* a_cls, float* a_diag, hipStream_t s) {
+  hipLaunchKernelGGL(fusion_row_diag_kernel, dim3((unsigned)cdiv(N, 256), (unsigned)B), dim3(256), 0, s, A, N, a_cls, a_diag);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+int fusion_mask_normalize(float* A, const int32_t* idx, int B, int N, int k, hipStream_t s) {
+  hipLaunchKernelGGL(fusion_mask_normalize_kernel, dim3((unsigned)cdiv(N, 4), (unsigned)B), dim3(256), (size_t)(k > 0 ? k : 1) * 4, s, A, idx, N, k);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
 int head_mean(const float* probs, int B, int H, int N, float* A, hipStream_t s) {
   const int64_t NN = (int64_t)N * N;
   hipLaunchKernelGGL(head_mean_kernel, dim3((unsigned)cdiv(NN, 256), (unsigned)B), dim3(256), 0, s, probs, H, NN, A);

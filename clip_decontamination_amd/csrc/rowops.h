@@ -68,6 +68,8 @@ size_t refine_scratch_bytes(int B, int D, int k);
 int neighbour_refine(float* tokens, int64_t sb, int64_t st, const int32_t* idx, int B, int gh, int gw, int D, int k,
                      int decontaminate, float contamination_temp, void* scratch, hipStream_t s);
 int head_mean(const float* probs, int B, int H, int N, float* A, hipStream_t s);
+int fusion_row_diag(const float* A, int B, int N, float* a_cls, float* a_diag, hipStream_t s);
+int fusion_mask_normalize(float* A, const int32_t* idx, int B, int N, int k, hipStream_t s);
 int attn_mode_enhance(float* tokens, int64_t sb, int64_t st, float* A, int B, int N, int D, float strength, float threshold, float* tmp,
                       hipStream_t s);
 

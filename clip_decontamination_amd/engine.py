@@ -109,10 +109,15 @@ class HipVisionTower:
             check(self.lib.sg_vit_finalize(self._ctx, s), "sg_vit_finalize")
 
     # -- options --------------------------------------------------------------------------------------
-    def forward_opts(self, model_type: str, ignore_residual: bool = True, apply_similarity_enhancement: bool = True) -> ForwardOpts:
+    def forward_opts(self, model_type: str, ignore_residual: bool = True, apply_similarity_enhancement: bool = True,
+                     apply_layer_fusion: bool = False, layer_fusion_lambda: float = 0.5) -> ForwardOpts:
         if model_type not in MODEL_TYPES:
             raise ValueError(f"unknown model_type {model_type!r}")
         o = ForwardOpts()
+        # attention-map layer fusion (transformer.py:598-607,630-637,647-690; semantics pinned by the one-head reference fixture,
+        # oracle/vit.py): not defined for GEM (its forward is replaced wholesale, gem_utils.py:159-199)
+        o.layer_fusion_enabled = int(bool(apply_layer_fusion) and model_type != "GEM")
+        o.layer_fusion_lambda = float(layer_fusion_lambda)
         o.model_type = MODEL_TYPES[model_type]
         o.ignore_residual = int(bool(ignore_residual))
         o.gem_depth = self.gem_depth
@@ -291,11 +296,9 @@ class HipCLIP:
     def encode_image(self, image, model_type, ignore_residual: bool = False, output_cls_token: bool = False, normalize: bool = False,
                      apply_layer_fusion: bool = False, layer_fusion_lambda: float = 0.5, layer_fusion_threshold: float = 0.7,
                      apply_similarity_enhancement: bool = False):
-        if apply_layer_fusion:
-            raise NotImplementedError("apply_layer_fusion is internally inconsistent in the reference (SURVEY.md R9) and is not built")
         v = self.visual
         win, idx = v._whole_image_windows(image)
-        opts = v.forward_opts(model_type, ignore_residual, apply_similarity_enhancement)
+        opts = v.forward_opts(model_type, ignore_residual, apply_similarity_enhancement, apply_layer_fusion, layer_fusion_lambda)
         cls, tok = v.forward_tiles(image, win, tuple(image.shape[-2:]), opts, idx)
         if normalize:
             cls = torch.nn.functional.normalize(cls, dim=-1)

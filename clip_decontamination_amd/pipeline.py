@@ -179,7 +179,8 @@ class SegPipeline:
                  ignore_residual: bool = True, cls_token_lambda: float = 0.0, global_debias_factor: float = 0.0,
                  logit_scale: float = 50.0, prob_thd: float = 0.0, bg_idx: int = 0, apply_similarity_enhancement: bool = False,
                  upsampler=None, tiles_per_launch: int = 32, cross_tile_fusion: Optional[dict] = None, apply_ctd: bool = False,
-                 tile_group=None):
+                 tile_group=None, apply_layer_fusion: bool = False, layer_fusion_lambda: float = 0.5):
+        self.apply_layer_fusion, self.layer_fusion_lambda = bool(apply_layer_fusion), float(layer_fusion_lambda)
         self.net = net
         self.visual = net.visual
         self.device = self.visual.device
@@ -225,7 +226,8 @@ class SegPipeline:
         th, tw = tile_hw
         l, r, t, b = compute_padsize(th, tw, P)
         gh, gw = (th + t + b) // P, (tw + l + r) // P
-        opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement)
+        opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement,
+                              getattr(self, "apply_layer_fusion", False), getattr(self, "layer_fusion_lambda", 0.5))
         win = torch.tensor(list(windows), dtype=torch.int32, device=self.device).reshape(-1, 4)
         outs = []
         fuse = self.cross_tile_fusion is not None and grid_of_tiles is not None and grid_of_tiles[0] * grid_of_tiles[1] > 1
@@ -374,7 +376,8 @@ class SegPipeline:
         gh, gw = (tile_hw[0] + t + b) // P, (tile_hw[1] + l + r) // P
         if self.upsampler is not None:
             raise NotImplementedError("cross-tile fusion together with the JBU upsampler is not wired")
-        opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement)
+        opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement,
+                              getattr(self, "apply_layer_fusion", False), getattr(self, "layer_fusion_lambda", 0.5))
         win = torch.tensor(list(mine), dtype=torch.int32, device=self.device).reshape(-1, 4)
         cls_all, tok_all = [], []
         for i in range(0, win.shape[0], self.tiles_per_launch):

@@ -220,7 +220,8 @@ class _HipSegmentorBase(_Base):
                            bg_idx=self.bg_idx, apply_similarity_enhancement=getattr(self, "apply_similarity_enhancement", False),
                            upsampler=self.upsampler, tiles_per_launch=self._tiles_per_launch,
                            cross_tile_fusion=getattr(self, "cross_tile_fusion_cfg", None), apply_ctd=getattr(self, "apply_ctd", False),
-                           tile_group=getattr(self, "tile_group", None))
+                           tile_group=getattr(self, "tile_group", None), apply_layer_fusion=getattr(self, "apply_layer_fusion", False),
+                           layer_fusion_lambda=getattr(self, "layer_fusion_lambda", 0.5))
 
     def forward_feature(self, img, logit_size=None, tile_h_idx=None, tile_w_idx=None):
         """Reference segmentor.py:286-392.  img [B,3,H,W] -> logits [B,Q,h,w]."""
@@ -338,8 +339,6 @@ class SegmentorEx(_HipSegmentorBase):
         if model_type == "GEM":
             raise ValueError("model_type='GEM' crashes in the reference SegmentorEx (it unpacks (cls, feats), SURVEY.md R5); "
                              "use segearth_segmentor.Segmentor with cls_token_lambda=0")
-        if _to_bool(apply_layer_fusion):
-            raise NotImplementedError("apply_layer_fusion is internally inconsistent in the reference (SURVEY.md R9) and is not built")
         visual = self._setup(clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                              slide_crop, cls_token_lambda, bg_idx, _to_bool(apply_sim_feat_up), sim_feat_up_cfg, global_debias_factor,
                              checkpoint, text_features, text_encoder, precision, synthetic_ok, tiles_per_launch, tokenizer=tokenizer,
@@ -347,7 +346,9 @@ class SegmentorEx(_HipSegmentorBase):
         # opt-in extra: kwargs of the reference's CrossTileFusion (cross_tile_fusion.py:24-60), which the reference never calls (R2)
         self.cross_tile_fusion_cfg = cross_tile_fusion_cfg
         self.apply_ctd = _to_bool(apply_ctd)                                # segmentor.py:184-194, 339-365: DBSCAN + cluster debias, on the device here
-        self.apply_layer_fusion, self.layer_fusion_lambda, self.layer_fusion_threshold = False, layer_fusion_lambda, layer_fusion_threshold
+        # attention-map layer fusion (segmentor.py:189-193, 302-304): the reference's own code only runs it with one head;
+        # built here with the semantics that case pins (oracle/vit.py).  layer_fusion_threshold is unused by the reference.
+        self.apply_layer_fusion, self.layer_fusion_lambda, self.layer_fusion_threshold = _to_bool(apply_layer_fusion), layer_fusion_lambda, layer_fusion_threshold
         self.apply_similarity_enhancement = _to_bool(apply_similarity_enhancement)
         if self.apply_similarity_enhancement:                               # segmentor.py:196-220
             c = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)

@@ -92,6 +92,11 @@ typedef struct sg_forward_opts {
   float   selfattn_strength;
   float   selfattn_threshold;
   int32_t gem_depth;              /* GEM: blocks -1..-(depth-1) are dual-stream (gem_wrapper.py:24-45) */
+  int32_t layer_fusion_enabled;   /* apply_layer_fusion (transformer.py:598-607,630-637,647-690): EMA of the head-averaged attention of every
+                                     block; with an outlier suppressor its top_k columns are zeroed, rows L1-renormalised and
+                                     output = attn @ output -- the refiners are then skipped, as in the reference.  The reference's
+                                     view(N, heads, L, L) only runs for heads == 1; that case pins the semantics. */
+  float   layer_fusion_lambda;
 } sg_forward_opts;
 
 /* Where the tiles of one launch come from: one scene + a window per tile, so that cropping,

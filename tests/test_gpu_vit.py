@@ -229,3 +229,38 @@ def test_tiny_selfattn_attention_mode_bf16(golden, tiny_bf16, mt):
     ref = torch.from_numpy(g[f"sa_attn.{mt}.tokens"])
     print(f"[{net.precision_tag}] sa_attn {mt}: max rel error {maxdiff(tok, ref) / ref.abs().max().item():.3e}")
     assert maxdiff(tok, ref) < HALF_TOL[net.precision_tag]["sa_attn"] * ref.abs().max().item()
+
+
+# ---- attention-map layer fusion (apply_layer_fusion, reference transformer.py:598-607,630-637,647-690) -----------------------------
+@pytest.mark.parametrize("tag,sim,lam,ign", [("lf", None, 0.5, True), ("lf_sim", SIM, 0.3, True), ("lf_res", None, 0.5, False)])
+@pytest.mark.parametrize("mt", ["SegEarth", "Experimental"])
+def test_layer_fusion_one_head_reference_fixture_f32(golden, tag, sim, lam, ign, mt):
+    """The one configuration the reference's own layer-fusion code runs in (heads == 1): fixture from the reference."""
+    cfg, net = tower("tiny-1h", "f32")
+    install(net, sim, dict(top_k=5))
+    g = golden("vit_tiny-1h")
+    cls, tok = net.encode_image(torch.from_numpy(g["img"]).to(DEV), mt, ign, output_cls_token=True, apply_layer_fusion=True,
+                                layer_fusion_lambda=lam, apply_similarity_enhancement=sim is not None)
+    assert maxdiff(tok, g[f"{tag}.{mt}.tokens"]) < 1e-4 and maxdiff(cls, g[f"{tag}.{mt}.cls"]) < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
+def test_layer_fusion_multi_head_vs_oracle(prec):
+    """heads > 1: the definition the one-head case pins (per-image head-averaged maps, as nn.MultiheadAttention returns them), against the
+    oracle restatement; and fusion without a suppressor leaves the output unchanged."""
+    cfg, net = tower("tiny-8", prec)
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    img = torch.from_numpy(np.random.default_rng(41).standard_normal((2, 3, 48, 48), dtype=np.float32))
+    for mt, sim in (("SegEarth", None), ("Experimental", SIM)):
+        install(net, sim, dict(top_k=5))
+        cls, tok = net.encode_image(img.to(DEV), mt, True, output_cls_token=True, apply_layer_fusion=True, layer_fusion_lambda=0.4,
+                                    apply_similarity_enhancement=sim is not None)
+        with torch.no_grad():
+            rc, rt = OV.vit_forward(w, cfg, img, mt, True, similarity_cfg=sim, outlier_cfg=dict(top_k=5), layer_fusion={"lambda": 0.4})
+        rel = maxdiff(tok, rt) / rt.abs().max().item()
+        print(f"[{prec}] layer fusion {mt}: max rel token error {rel:.3e}")
+        assert rel < {"f32": 1e-5, "bf16": 0.02, "f16": 3e-3}[prec]
+    install(net)
+    a = net.encode_image(img.to(DEV), "SegEarth", True, output_cls_token=True, apply_layer_fusion=True)[1]
+    b = net.encode_image(img.to(DEV), "SegEarth", True, output_cls_token=True)[1]
+    assert torch.equal(a, b)

@@ -148,6 +148,29 @@ def test_jbu(golden, name):
     assert maxdiff(OJ.adaptive_conv(t(g["ac_in"]), t(g["ac_filt"])), g["ac_out"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag,sim,lam,ign", [("lf", None, 0.5, True), ("lf_sim", SIM, 0.3, True), ("lf_res", None, 0.5, False)])
+@pytest.mark.parametrize("mt", ["SegEarth", "Experimental"])
+def test_layer_fusion_matches_the_one_head_reference(golden, tag, sim, lam, ign, mt):
+    """apply_layer_fusion + outlier suppressor: the reference runs only with ONE head (its view(N, heads, L, L) of already
+    head-averaged weights) -- that run pins the restatement (fixture vit_tiny-1h from oracle.gen_golden --only layer_fusion)."""
+    g = golden("vit_tiny-1h")
+    cfg = Wt.vit_config("tiny-1h")
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    with torch.no_grad():
+        cls, tok = OV.vit_forward(w, cfg, t(g["img"]), mt, ign, similarity_cfg=sim, outlier_cfg=dict(top_k=5), layer_fusion={"lambda": lam})
+    assert maxdiff(tok, g[f"{tag}.{mt}.tokens"]) < 2e-5 and maxdiff(cls, g[f"{tag}.{mt}.cls"]) < 2e-5
+
+
+def test_layer_fusion_without_suppressor_is_a_noop(golden):
+    g = golden("vit_tiny-1h")
+    cfg = Wt.vit_config("tiny-8")
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    with torch.no_grad():
+        _, tok = OV.vit_forward(w, cfg, t(g["img"]), "SegEarth", True, layer_fusion={"lambda": 0.5})
+        _, tok0 = OV.vit_forward(w, cfg, t(g["img"]), "SegEarth", True)
+    assert torch.equal(tok, tok0) and maxdiff(tok, g["noop8.tokens"]) < 2e-5
+
+
 def test_jbu_on_the_trained_checkpoint(golden):
     """JBUStack(512) on the COCO-Stuff weights the reference ships (fixture minted by oracle.gen_golden --only jbu_real from the
     reference module + its own checkpoint): trained range_temp / sigma_spatial / fixup weights."""
