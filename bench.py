@@ -41,7 +41,7 @@ TILE_COLS, TILE_ROWS_PER_RANK = 16, 8        # default: 128 tiles per rank per s
 PEAK_BF16_TFLOPS = 2500.0                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def build_pipeline(device, precision, tiles_per_launch):
+def build_pipeline(device, precision, tiles_per_launch, upsampler="none"):
     from clip_decontamination_amd.engine import HipVisionTower, HipCLIP, SimilarityEnhancementModule, OutlierSuppressionModule
     from clip_decontamination_amd.pipeline import SegPipeline
     cfg = Wt.vit_config("ViT-L-14")
@@ -49,9 +49,14 @@ def build_pipeline(device, precision, tiles_per_launch):
     tower.similarity_enhancer = SimilarityEnhancementModule(1.0, 1.0, True)
     tower.outlier_suppressor = OutlierSuppressionModule(top_k=30)
     text = torch.from_numpy(Wt.make_text_features(len(POTSDAM_QIDX), cfg.embed_dim))
+    up = None
+    if upsampler != "none":                              # BASELINE configs[3]: ViT-L/14 + SimFeatUp JBU (synthetic upsampler weights, seed 3)
+        from clip_decontamination_amd.upsampler import HipJBU
+        up = HipJBU(upsampler, cfg.embed_dim, device, precision)
+        up.load_state_dict(Wt.make_jbu_weights(upsampler, cfg.embed_dim, seed=3))
     pipe = SegPipeline(HipCLIP(tower), text, torch.tensor(POTSDAM_QIDX), model_type="Experimental", ignore_residual=True,
                        global_debias_factor=0.2, prob_thd=0.1, bg_idx=5, apply_similarity_enhancement=True,
-                       tiles_per_launch=tiles_per_launch)
+                       tiles_per_launch=tiles_per_launch, upsampler=up)
     return cfg, pipe
 
 
@@ -98,6 +103,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=TILE_ROWS_PER_RANK, help="tile rows per rank (weak scaling: the scene grows with the ranks)")
     ap.add_argument("--tiles-per-launch", type=int, default=0, help="0 = all of a rank's tiles in one launch of the tower")
     ap.add_argument("--streams", type=int, default=1, help="experiment: split a rank's tiles over this many HIP streams (tails of one half overlap the other)")
+    ap.add_argument("--upsampler", default="none", choices=["none", "jbu_one", "jbu_stack"],
+                    help="per-pixel logits through the SimFeatUp JBU upsampler (BASELINE configs[3]); multi-rank: halo tiles travel point to point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -124,12 +131,15 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from clip_decontamination_amd import _lib, ops
-    from clip_decontamination_amd.pipeline import tile_windows
+    from clip_decontamination_amd.pipeline import band_plan, exchange_halo_tiles, gather_blocks, partition, tile_windows
     lib = _lib.load()
+    jbu = args.upsampler != "none"
+    if jbu and args.tile_rows == TILE_ROWS_PER_RANK and args.tile_cols == TILE_COLS:
+        args.tile_rows, args.tile_cols = 4, 8            # per-pixel logits are 11 MB per tile: 32 tiles per rank per step by default
     TILE_COLS, TILE_ROWS_PER_RANK = args.tile_cols, args.tile_rows
     if args.tiles_per_launch <= 0:
-        args.tiles_per_launch = TILE_COLS * TILE_ROWS_PER_RANK
-    cfg, pipe = build_pipeline(device, args.precision, args.tiles_per_launch)
+        args.tiles_per_launch = min(TILE_COLS * TILE_ROWS_PER_RANK, 32 if jbu else 1 << 30)
+    cfg, pipe = build_pipeline(device, args.precision, args.tiles_per_launch, args.upsampler)
 
     # scene: TILE_COLS x (TILE_ROWS_PER_RANK * world) tiles of 512 at stride 256, uint8 NHWC, resident in HBM
     rows_total = TILE_ROWS_PER_RANK * world
@@ -148,6 +158,10 @@ def main():
     win_all = torch.tensor(wins, dtype=torch.int32, device=device)
     l, r, t, b = 3, 3, 3, 3                                           # compute_padsize(512, 512, 14)
     up = (TILE + t + b, TILE + l + r)
+    T_all = len(wins)
+    assert partition(T_all, world, rank) == (rank * len(my), (rank + 1) * len(my))       # the pipeline's own block partition
+    plan = band_plan(wins, H, world)                                  # canvas bands + the tile range each band needs (pipeline.py)
+    group = dist.group.WORLD if world > 1 else None
 
     side = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else []
 
@@ -169,20 +183,23 @@ def main():
     last = {}
 
     def step():
-        tl = tower()                                                  # [tiles of this rank, Q, 37, 37]
+        tl = tower()                                                  # [tiles of this rank, Q, 37, 37]  (or [.., Q, 592, 592] with the upsampler)
         last["tl"] = tl
-        if world > 1:
-            gathered = [torch.empty_like(tl) for _ in range(world)]
-            dist.all_gather(gathered, tl)                             # RCCL over xGMI: 44 kB per tile
-            tl_all = torch.cat(gathered, 0)
+        # The product's own sharding helpers (pipeline.sharded_canvas_band does exactly this on a scene every rank holds; here every
+        # rank only holds the scene rows of its own tiles, so the steps are spelled out):
+        #   patch-grid logits (44 kB per tile): ONE all_gather_into_tensor rebuilds the tile list everywhere (RCCL over xGMI);
+        #   per-pixel logits (upsampler, 11 MB per tile): only the tiles that straddle a band edge travel, point to point.
+        a_t, b_t = plan[1][rank]
+        if world > 1 and not jbu:
+            tiles = gather_blocks(tl, T_all, world, rank, group)[a_t:b_t]
+        elif world > 1:
+            tiles, a_t = exchange_halo_tiles(tl, wins, world, rank, group, plan)
         else:
-            tl_all = tl
-        # this rank stitches + labels its own band of canvas rows (tiles that do not overlap the band contribute nothing)
-        lo_t = max(0, (y_lo - TILE) // STRIDE) * TILE_COLS
-        hi_t = min(len(wins), ((y_hi + STRIDE - 1) // STRIDE + 1) * TILE_COLS)
-        w_band = win_all[lo_t:hi_t].clone()
+            tiles = tl
+        # this rank stitches + labels ITS band of canvas rows
+        w_band = win_all[a_t:a_t + tiles.shape[0]].clone()
         w_band[:, 0:2] -= y_lo
-        canvas = ops.stitch(tl_all[lo_t:hi_t], w_band, up, (t, l), (y_hi - y_lo, W))
+        canvas = ops.stitch(tiles, w_band, up, (t, l), (y_hi - y_lo, W))
         probs, labels = pipe.postprocess(canvas, want_probs=False)
         return labels
 
@@ -253,9 +270,12 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "ViT-L/14, 512x512x3 uint8 tiles at stride 256 (padded to 518, N=1370 tokens), "
                                    "model_type=Experimental + similarity enhancement + outlier suppression k=30 + global debias 0.2, "
+                                   + ("SimFeatUp JBU upsampler to per-pixel logits, " if jbu else "") +
                                    "8 Potsdam queries / 6 classes, slide stitch + arg-max labels",
                        "tiles_per_step_per_gpu": TILE_ROWS_PER_RANK * TILE_COLS, "tiles_per_launch": args.tiles_per_launch,
-                       "scene": f"{H}x{W}", "partition": f"tile rows over {world} rank(s), all-gather of patch-grid logits"},
+                       "scene": f"{H}x{W}", "upsampler": args.upsampler,
+                       "partition": (f"tile rows over {world} rank(s), " + ("point-to-point halo exchange of per-pixel tile logits" if jbu
+                                     else "all-gather of patch-grid logits") + ", band-local stitch + labels")},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_persist", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic()[0], "traffic_note": pmc_traffic()[1],
                          "launches": g_n, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
@@ -268,7 +288,11 @@ def main():
                                                 "attention": round(a_ms / (dt * 1e3), 4)}},
         }
         out["self_check"] = batched_check
-        if world == 1 and not args.no_cpu_baseline:
+        if jbu:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = ("not timed with the upsampler: the oracle's JBU (the reference's unfold form) needs ~12 GB and ~70 s per 512-pixel "
+                                        "tile (BASELINE.md); parity of this path: tests/test_gpu_configs.py::test_config4_l14_jbu_isaid")
+        elif world == 1 and not args.no_cpu_baseline:
             kept = []
             out["cpu_baseline"] = cpu_baseline(cfg, keep=kept)
             # (b) the CPU-baseline tiles through the HIP path (same precision mode as the timed run): logits vs the oracle's

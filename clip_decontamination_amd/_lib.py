@@ -47,7 +47,6 @@ SIGNATURES = {
     "sg_profile_enable": (I, [I]),
     "sg_profile_disable": (I, []),
     "sg_set_gemm_config": (I, [I]),
-    "sg_set_gemm_tuning": (I, [I, I]),
     "sg_profile_read": (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(L), C.POINTER(L)]),
     "sg_create": (I, [C.POINTER(P), I, C.POINTER(VitDesc)]),
     "sg_destroy": (None, [P]),

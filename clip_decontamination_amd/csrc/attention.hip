@@ -181,17 +181,17 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-          float bvv = 0.f;
-          if (key >= 1 && key < a.N && q_ld >= 1) {
-            const int64_t off = (int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1);
-            if (a.bias_kind == HK_F32) bvv = a.bias[off];
-            else {
-              const bf16_t raw = reinterpret_cast<const bf16_t*>(a.bias)[off];
-              bvv = a.bias_kind == HK_F16 ? h2f(f16_t{raw}) : bf2f(raw);
-            }
+          const bool in = key >= 1 && key < a.N && q_ld >= 1;
+          const int64_t off = (int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1);
+          if (a.bias_kind == HK_F32) {
+            float bvv = in ? a.bias[off] : 0.f;
+            if (a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
+            bnext[i] = bvv;
+          } else {
+            // 2-byte map (the tower's own similarity map): keep the RAW bits -- converting here would make every load wait for its
+            // data inside this prefetch loop (one exposed latency per element instead of one per tile); converted where it is used
+            bnext[i] = __uint_as_float(in ? (uint32_t)reinterpret_cast<const bf16_t*>(a.bias)[off] : 0u);
           }
-          if (a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
-          bnext[i] = bvv;
         }
       }
     };
@@ -253,7 +253,11 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = k0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-          const float bv = a.bias ? bnext[i] * a.bias_w : 0.f;
+          float bv = 0.f;
+          if (a.bias) {
+            const uint32_t raw = __float_as_uint(bnext[i]);
+            bv = (a.bias_kind == HK_F32 ? bnext[i] : (a.bias_kind == HK_F16 ? h2f(f16_t{(uint16_t)raw}) : __uint_as_float(raw << 16))) * a.bias_w;
+          }
           float v = sacc[i >> 4][i & 15] * c2;
           if (a.resoftmax) v = (__builtin_amdgcn_exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
           sc[i] = (key < a.N && !(a.causal && key > q_glob)) ? v : -INFINITY;   // causal: text tower (build_causal_mask)

@@ -404,10 +404,6 @@ extern "C" int sg_set_gemm_config(int cfg) {
   set_gemm_config(cfg);
   return SG_OK;
 }
-extern "C" int sg_set_gemm_tuning(int key, int value) {
-  set_gemm_tuning(key, value);
-  return SG_OK;
-}
 extern "C" int sg_profile_disable(void) { g_prof.on = false; return SG_OK; }
 // category: 0 bf16 GEMM (non-persistent tile variants), 1 fused attention, 2 f32 GEMM, 3 the persistent bf16 GEMM, 4 fp8 GEMM.  Call after the stream
 // has been synchronised.

@@ -158,12 +158,8 @@ struct GemmBf16Args {
   // rowdot[m * rowdot_ld + n / 64] = sum over the 64 columns [n, n + 64) of v * (2 r + v)  (= |r + v|^2 - |r|^2 of that column slice):
   // the JBU tail needs only the norm of x + 0.1 * conv1x1(x), never the C x S^2 map itself.  f32 residual required.
   float* rowdot; int64_t rowdot_ld;
-  // persistent kernel only: start-up stagger in shader cycles (0 = none).  Workgroup w sleeps phase(w) * stagger cycles before its
-  // first tile so that the HBM-heavy epilogues of the 256 workgroups (all tiles take the same time) do not all fall together.
-  int stagger;
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
-void set_gemm_tuning(int key, int value);   // tuning hook (per calling thread): key 0 = stagger cycles override (-1 = automatic)
 void set_gemm_config(int c);   // tuning hook (per calling thread): -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
 
 // f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];

@@ -748,9 +748,6 @@ static int launch_pp32(const GemmBf16Args& a, hipStream_t s) {
   return SG_OK;
 }
 
-static thread_local int g_gemm_tuning[4] = {-1, -1, -1, -1};   // tuning overrides of the calling thread (sg_set_gemm_tuning)
-void set_gemm_tuning(int key, int value) { if (key >= 0 && key < 4) g_gemm_tuning[key] = value; }
-
 // ---- persistent ping-pong: the production kernel for the large ViT linears ---------------------------------------------------------
 // gemm_bf16_pp32's ring (K tile 32, four slots) with three changes measured to matter:
 //   * ONE phase of 32 MFMAs per K tile (12 ds_read_b128 + 4 global_load_lds per wave per READ segment): the barrier + LDS-latency
@@ -936,16 +933,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
     __builtin_amdgcn_sched_barrier(0);               \
   } while (0)
 
-  // Start-up stagger: every output tile takes the same time, so without it all workgroups of the chip run their mainloops
-  // (L2-fed, HBM nearly idle) and their epilogues (HBM-bound: residual read + C write) in lockstep and the two never overlap.
-  // phase = a bit-reversed 5-bit index of the workgroup inside its XCD (+ an XCD offset): neighbours in dispatch order get far-apart phases.
-  if (a.stagger > 0) {
-    const unsigned w = blockIdx.x >> 3, x = blockIdx.x & 7;
-    const unsigned rev = ((w & 1) << 4) | ((w & 2) << 2) | (w & 4) | ((w & 8) >> 2) | ((w & 16) >> 4);
-    const unsigned ph = (rev * 8 + ((x * 5) & 7)) & 255;                  // 0..255
-    const long long until = (long long)__builtin_amdgcn_s_memtime() + ((long long)a.stagger * ph >> 8);
-    while ((long long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
-  }
   // prologue (group 0 holds W(2) back: it is issued in READ(0) as W(s+2))
   load_a(0); load_w(0); load_a(1); load_w(1); load_a(2);
   if (g == 1) load_w(2);
@@ -1004,9 +991,7 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
-  GemmBf16Args b = a;
-  if (g_gemm_tuning[0] >= 0) b.stagger = g_gemm_tuning[0];
-  hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, b, a.act, a.c_is_bf16);
+  hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
   return SG_OK;
 }
 

@@ -104,12 +104,23 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
   const int ty0 = (blockIdx.x / tiles_x) * AC_T, tx0 = (blockIdx.x % tiles_x) * AC_T;
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t img = (int64_t)b * H * W;
-  for (int i = tid; i < WT * WT * (KEY_DIM / 4); i += 256) {
-    const int pos = i / (KEY_DIM / 4), q = i % (KEY_DIM / 4);
-    int sy = ty0 + pos / WT - r, sx = tx0 + pos % WT - r;
-    sy = sy > H - 1 + r ? H - 1 + r : sy; sx = sx > W - 1 + r ? W - 1 + r : sx;      // ragged last tile: stay inside the padded image
-    sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
-    *reinterpret_cast<float4*>(jk_sm + pos * JK_LD + 4 * q) = *reinterpret_cast<const float4*>(proj + (img + (int64_t)sy * W + sx) * KEY_DIM + 4 * q);
+  for (int i0 = 0; i0 < WT * WT * (KEY_DIM / 4); i0 += 256 * 4) {          // four 16-byte pieces per thread in flight per round
+    float4 pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + tid + u * 256;
+      i = i < WT * WT * (KEY_DIM / 4) ? i : WT * WT * (KEY_DIM / 4) - 1;
+      const int pos = i / (KEY_DIM / 4), q = i % (KEY_DIM / 4);
+      int sy = ty0 + pos / WT - r, sx = tx0 + pos % WT - r;
+      sy = sy > H - 1 + r ? H - 1 + r : sy; sx = sx > W - 1 + r ? W - 1 + r : sx;    // ragged last tile: stay inside the padded image
+      sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
+      pv[u] = *reinterpret_cast<const float4*>(proj + (img + (int64_t)sy * W + sx) * KEY_DIM + 4 * q);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + tid + u * 256;
+      if (i < WT * WT * (KEY_DIM / 4)) *reinterpret_cast<float4*>(jk_sm + (i / (KEY_DIM / 4)) * JK_LD + 4 * (i % (KEY_DIM / 4))) = pv[u];
+    }
   }
   __syncthreads();
   const float temp = fminf(fmaxf(expf(range_temp[0]), 1e-4f), 1e4f);
@@ -428,11 +439,23 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
       row[c] += wt[k];
     }
   }
-  for (int i = tid; i < D2 * 64; i += 256) {
-    const int pxl = i / D2, t = i % D2;                                    // coalesced along the taps of one pixel
-    int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
-    y = y < H ? y : H - 1; x = x < W ? x : W - 1;
-    sK[pxl * D2 + t] = Kf[(((int64_t)b * H + y) * W + x) * ldk + t];
+  {
+    constexpr int NK = (D2 * 64 + 255) / 256;                              // loads per thread: issued back to back, stored afterwards
+    float kv[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      int i = tid + u * 256;
+      i = i < D2 * 64 ? i : D2 * 64 - 1;
+      const int pxl = i / D2, t = i % D2;                                  // coalesced along the taps of one pixel
+      int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+      y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+      kv[u] = Kf[(((int64_t)b * H + y) * W + x) * ldk + t];
+    }
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      const int i = tid + u * 256;
+      if (i < D2 * 64) sK[i] = kv[u];                                      // sK[pxl * D2 + t] with i = pxl * D2 + t
+    }
   }
   __syncthreads();
   // ---- 2. Keff = Wy^T . K . Wx for pixel p, window columns 3q..3q+2 ----
@@ -474,15 +497,24 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
   for (int c0 = 0; c0 < C; c0 += ACM_CC) {
     __syncthreads();                                                       // F complete / Keff build done with sK / previous chunk's MFMAs done with sW
     // ---- 3a. window [pos][128 ch] as it lies in HBM: 16 x 16-byte pieces per position ----
-    for (int i = tid; i < KP * (ACM_CC / 8); i += 256) {
-      const int pos = i / (ACM_CC / 8), qc = i % (ACM_CC / 8);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pos < L::NPOS && c0 + 8 * qc < C) {
-        int sy = ly0 + pos / LW, sx = lx0 + pos % LW;
-        sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy); sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);   // weight 0 outside: any finite value
-        v = *reinterpret_cast<const uint4*>(sb + ((int64_t)sy * w + sx) * C + c0 + 8 * qc);
+    {
+      constexpr int NS = KP * (ACM_CC / 8) / 256;                          // 16-byte pieces per thread: all in flight before the first LDS store
+      static_assert(KP * (ACM_CC / 8) % 256 == 0, "window pieces must divide over the threads");
+      uint4 wv[NS];
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const int i = tid + u * 256, pos = i / (ACM_CC / 8), qc = i % (ACM_CC / 8);
+        const int pc = pos < L::NPOS ? pos : L::NPOS - 1;                  // K padding rows: F is zero there, any finite value will do
+        int sy = ly0 + pc / LW, sx = lx0 + pc % LW;
+        sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy); sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);   // weight 0 outside the image too
+        int cc = c0 + 8 * qc; cc = cc + 8 <= C ? cc : C - 8;               // ragged last chunk: a valid duplicate, never stored
+        wv[u] = *reinterpret_cast<const uint4*>(sb + ((int64_t)sy * w + sx) * C + cc);
       }
-      *reinterpret_cast<uint4*>(sW + pos * LDW + 8 * qc) = v;
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const int i = tid + u * 256, pos = i / (ACM_CC / 8), qc = i % (ACM_CC / 8);
+        *reinterpret_cast<uint4*>(sW + pos * LDW + 8 * qc) = wv[u];
+      }
     }
     __syncthreads();
     // ---- 3b. wave: channels [32 wave, +32) x 64 pixels ----
@@ -877,19 +909,20 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
 //     |out|^2     = |x|^2 + sum_c z (2 x + z)                                                       (the GEMM's row-dot epilogue)
 // so the only C x C GEMM keeps its result in registers and HBM sees x once more (f32) plus Q floats per pixel.
 namespace sg {
-__global__ void jbu_geff_kernel(const float* __restrict__ text, const float* __restrict__ Wf, const float* __restrict__ bf01, int C, int Q,
-                                float* __restrict__ geff, float* __restrict__ g0) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;            // (c, q)
-  if (i < C * Q) {
-    const int c = i / Q, q = i % Q;
+__global__ __launch_bounds__(256) void jbu_geff_kernel(const float* __restrict__ text, const float* __restrict__ Wf, const float* __restrict__ bf01,
+                                                       int C, int Q, float* __restrict__ geff, float* __restrict__ g0) {
+  const int c = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;             // thread = channel: Wf[k][c] reads are coalesced over c
+  const float* tq = text + (int64_t)q * C;
+  if (c < C) {
     float a = 0.f;
-    for (int k = 0; k < C; ++k) a += Wf[(int64_t)k * C + c] * text[(int64_t)q * C + k];   // (Wf^T T^T)[c, q]
-    geff[c * JBU_QMAX + q] = text[(int64_t)q * C + c] + 0.1f * a;
+    for (int k = 0; k < C; ++k) a += Wf[(int64_t)k * C + c] * tq[k];         // (Wf^T T^T)[c, q]
+    geff[c * JBU_QMAX + q] = tq[c] + 0.1f * a;
   }
-  if (i < Q) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
     float a = 0.f;
-    for (int k = 0; k < C; ++k) a += bf01[k] * text[(int64_t)i * C + k];                  // bf01 = 0.1 * bias (scaled at load)
-    g0[i] = a;
+    for (int k = threadIdx.x; k < C; k += 64) a += bf01[k] * tq[k];          // bf01 = 0.1 * bias (scaled at load)
+    a = wave_sum(a);
+    if (threadIdx.x == 0) g0[q] = a;
   }
 }
 // cls_logits[b, q] = (cls[b] / |cls[b]|) . T[q]     (segmentor.py:309-311)
@@ -907,47 +940,59 @@ __global__ __launch_bounds__(64) void jbu_cls_logits_kernel(const float* __restr
     if (lane == 0) out[b * JBU_QMAX + q] = d * inv;
   }
 }
-// 8 lanes per pixel: each lane owns C/8 channels (float4 strided by 8 lanes: 128 B contiguous per step), Q running dots + |x|^2 in
-// registers, 3 shuffle steps to combine; Geff lives in LDS (C x QP floats).
+// One wave = 64 consecutive pixels, lane = pixel.  x rows are fetched coalesced (8 lanes x 16 B per pixel row piece) into a per-wave LDS
+// tile [64 px][32 ch] and read back pixel-per-lane (row stride 36 floats: conflict-free b128), so every lane walks ITS pixel's channels
+// while Geff[c][:] comes from LDS as a broadcast read -- Q running dots + |x|^2 per lane, no cross-lane reduction, and the logits of a
+// query go out as 256 contiguous bytes per wave.  LDS traffic per pixel: 2 x C x 4 B (tile) instead of C x Q x 4 B.
+constexpr int PL_LD = 36;
 template <int QP>
-__global__ __launch_bounds__(256) void jbu_pixel_logits_kernel(const float* __restrict__ x, const float* __restrict__ rowdot, int slots,
+__global__ __launch_bounds__(256, 2) void jbu_pixel_logits_kernel(const float* __restrict__ x, const float* __restrict__ rowdot, int slots,
                                                                const float* __restrict__ geff, const float* __restrict__ g0,
                                                                const float* __restrict__ clsl, float lambda, int64_t pixels, int64_t P, int C,
                                                                int Q, float* __restrict__ logits) {
-  extern __shared__ __attribute__((aligned(16))) float sG[];     // [C][QP], 4 pad floats after every 4 channels: the 8 lanes of a pixel
-  for (int i = threadIdx.x; i < C * QP; i += 256) {               // (channels 4 apart) read 8 different bank groups
-    const int c = i / QP, q = i % QP;
-    sG[c * QP + (c >> 2) * 4 + q] = q < Q ? geff[c * JBU_QMAX + q] : 0.f;
-  }
+  extern __shared__ __attribute__((aligned(16))) float pl_sm[];
+  float* sG = pl_sm;                                              // [C][QP]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* tile = pl_sm + (size_t)C * QP + wave * 64 * PL_LD;       // [64][PL_LD], private to the wave
+  for (int i = threadIdx.x; i < C * QP; i += 256) sG[i] = (i % QP) < Q ? geff[(i / QP) * JBU_QMAX + (i % QP)] : 0.f;
   __syncthreads();
-  const int sub = threadIdx.x & 7;
-  const int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-  const bool live = pix < pixels;
-  const float* xr = x + (live ? pix : 0) * C;
+  const int64_t pix0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  if (pix0 >= pixels) return;
   float acc[QP], nx = 0.f;
 #pragma unroll
   for (int q = 0; q < QP; ++q) acc[q] = 0.f;
-  for (int c = sub * 4; c < C; c += 32) {
-    const float4 v = *reinterpret_cast<const float4*>(xr + c);
-    nx += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    const float* g = sG + c * QP + c;                            // c is a multiple of 4: (c >> 2) * 4 == c
+  const int lp = lane >> 3, lc = lane & 7;                        // load role: pixel (within a group of 8) and 16-byte piece of its 128-byte row piece
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    float4 v[8];
 #pragma unroll
-    for (int q = 0; q < QP; ++q) acc[q] += v.x * g[q] + v.y * g[QP + q] + v.z * g[2 * QP + q] + v.w * g[3 * QP + q];
+    for (int u = 0; u < 8; ++u) {
+      int64_t pr = pix0 + u * 8 + lp;
+      pr = pr < pixels ? pr : pixels - 1;
+      v[u] = *reinterpret_cast<const float4*>(x + pr * C + c0 + 4 * lc);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(tile + (u * 8 + lp) * PL_LD + 4 * lc) = v[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // LDS executes a wave's instructions in order: ordering only, no barrier
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+    for (int k = 0; k < 8; ++k) {
+      const float4 xv = *reinterpret_cast<const float4*>(tile + lane * PL_LD + 4 * k);
+      nx += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+      const float* g = sG + (size_t)(c0 + 4 * k) * QP;            // same address on every lane: broadcast
+#pragma unroll
+      for (int q = 0; q < QP; ++q) acc[q] += xv.x * g[q] + xv.y * g[QP + q] + xv.z * g[2 * QP + q] + xv.w * g[3 * QP + q];
+    }
+    __builtin_amdgcn_wave_barrier();                              // the tile is rewritten in the next round
   }
-#pragma unroll
-  for (int o = 1; o < 8; o <<= 1) {
-    nx += __shfl_xor(nx, o, 64);
-#pragma unroll
-    for (int q = 0; q < QP; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
-  }
-  if (!live) return;
+  const int64_t pix = pix0 + lane;
+  if (pix >= pixels) return;
   float n2 = nx;
   for (int sidx = 0; sidx < slots; ++sidx) n2 += rowdot[pix * slots + sidx];          // fixed order: deterministic
   const float inv = 1.0f / sqrtf(n2);
   const int64_t b = pix / P, pp = pix % P;
 #pragma unroll
   for (int q = 0; q < QP; ++q)
-    if (q < Q && (q & 7) == sub) {
+    if (q < Q) {
       float v = (acc[q] + g0[q]) * inv;
       if (clsl) v += lambda * clsl[b * JBU_QMAX + q];
       logits[(b * Q + q) * P + pp] = v;
@@ -974,7 +1019,7 @@ extern "C" int sg_jbu_logits(sg_jbu* j, const float* source, const float* guidan
   SG_REQUIRE(pixels >= 1024 && pixels < (1ll << 31), "sg_jbu_logits: pixel count out of range");
   const float* x = nullptr;
   SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &x, s));
-  hipLaunchKernelGGL(jbu_geff_kernel, dim3((unsigned)cdiv((int64_t)C * Q, 256)), dim3(256), 0, s, text, j->fin_w, j->fin_b, C, Q, p.geff, p.g0);
+  hipLaunchKernelGGL(jbu_geff_kernel, dim3((unsigned)cdiv(C, 256), (unsigned)Q), dim3(256), 0, s, text, j->fin_w, j->fin_b, C, Q, p.geff, p.g0);
   SG_LAUNCH_CHECK();
   const bool use_cls = cls != nullptr && cls_token_lambda != 0.f;
   if (use_cls) { hipLaunchKernelGGL(jbu_cls_logits_kernel, dim3(B), dim3(64), 0, s, cls, text, C, Q, p.clsl); SG_LAUNCH_CHECK(); }
@@ -984,10 +1029,10 @@ extern "C" int sg_jbu_logits(sg_jbu* j, const float* source, const float* guidan
   g.rowdot = p.rowdot; g.rowdot_ld = C / 64;
   SG_TRY(gemm_bf16(g, s));
   const int slots = C / 64;
-  const unsigned grid = (unsigned)cdiv(pixels, 32);
+  const unsigned grid = (unsigned)cdiv(pixels, 256);
 #define SG_JBU_PIX(QP)                                                                                                        \
   do {                                                                                                                         \
-    const size_t lds = (size_t)(C * QP + C) * sizeof(float);                                                                   \
+    const size_t lds = ((size_t)C * QP + 4 * 64 * PL_LD) * sizeof(float);                                                      \
     if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_pixel_logits_kernel<QP>), lds));         \
     hipLaunchKernelGGL(jbu_pixel_logits_kernel<QP>, dim3(grid), dim3(256), lds, s, x, p.rowdot, slots, p.geff, p.g0,           \
                        use_cls ? p.clsl : nullptr, cls_token_lambda, pixels, P, C, Q, logits);                                 \

@@ -126,7 +126,6 @@ int sg_version(void);
 int sg_profile_enable(int capacity);
 int sg_profile_disable(void);
 int sg_set_gemm_config(int cfg);   /* tuning hook (calling thread only): bf16 GEMM tile variant, -1 = automatic */
-int sg_set_gemm_tuning(int key, int value);   /* tuning hook (calling thread only): key 0 = start-up stagger of the persistent GEMM in shader cycles, -1 = automatic */
 int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped);
 
 /* ---- context and weights ------------------------------------------------------------------
