@@ -317,7 +317,7 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
     p.h8 = (uint8_t*)b.take(R * d.mlp_width); p.sh8 = b.get<float>(R);
   }
   p.xhat = nullptr; p.sim = nullptr;
-  if (o->similarity_enabled) { p.xhat = b.take((size_t)B * n * d.width * e); p.sim = (float*)b.take((size_t)B * n * n * (c->hk ? 2 : 4)); }   // throughput modes: map kept in the operand type
+  if (o->similarity_enabled) { p.xhat = b.take((size_t)B * n * d.width * e); p.sim = b.get<float>((size_t)B * n * n); }
   p.lse = b.get<float>((size_t)B * d.heads * N);
   p.lse1 = b.get<float>((size_t)B * d.heads * N);
   p.attn_cls = b.get<float>((size_t)B * N);
@@ -685,7 +685,9 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
       }
     }
     if (o->similarity_enabled)
-      SG_TRY(similarity_from_xhat(c->hk, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s, c->hk != HK_F32));
+      // the map stays f32 (similarity_enhancement.py computes it in fp32): a 2-byte map (sim_half, bias_kind of the attention kernel) halves
+      // the bias fetch but measured no faster -- the 'Experimental' kernel is bound by its two exponentials per score, not by the fetch
+      SG_TRY(similarity_from_xhat(c->hk, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s, false));
     // ---- last block: self-self attention on ln_1(x), no residual / MLP when ignore_residual (transformer.py:627-643) ----
     const LayerW& LL = c->layers[L - 1];
     AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1, p.omega, p.qnorm, p.knorm};
@@ -703,7 +705,7 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     const void* ctx = p.ctx; int64_t ctx_ld = D;
     if (o->model_type == SG_MASKCLIP) { ctx = (const char*)p.qkv + (size_t)2 * D * c->esz; ctx_ld = 3 * D; }   // identity attention: ctx = v
     else SG_TRY(run_attention(c->hk, p.qkv, B, N, D, H, o->model_type, (o->similarity_enabled && o->model_type < SG_NACLIP) ? p.sim : nullptr, o->similarity_weight,
-                              nullptr, p.ctx, false, ab, s, false, c->hk));
+                              nullptr, p.ctx, false, ab, s, false, HK_F32));
     SG_TRY(linear(c->hk, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
     if (!o->ignore_residual) SG_TRY(mlp_block(c, LL, p.out_last, p, R, s));
     // ---- attention-map layer fusion: mask the fused map's outlier columns, renormalise, re-weight every token (transformer.py:647-690) ----

@@ -777,7 +777,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
   }
   // f32 output with residual: the residual of strip t + RD is requested while strip t goes through the patch, so RD strips of HBM
   // latency are in flight per wave instead of one dependent load -> add -> store chain per strip (addresses clamped, stores guarded)
-  constexpr int RD = 4;
+  constexpr int RD = 5;
   constexpr int LPRF = TN / 4, RPPF = 64 / LPRF, NPASS = 8 / RPPF;
   float4 rbuf[RD][NPASS];
   auto fetch_res = [&](int t, float4 (&dst)[NPASS]) {

@@ -137,46 +137,73 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
     const float fi = -1.0f + (float)ti * step, fj = -1.0f + (float)tj * step;
     sp[s2] = tv[s2] ? expf(-(fi * fi + fj * fj) / (2.0f * sg * sg)) : 0.f;
   }
-  for (int pp = 0; pp < 16; ++pp) {
-    const int pxl = wave * 16 + pp, py = pxl >> 3, px = pxl & 7;
-    const int y = ty0 + py, x = tx0 + px;
-    if (y >= H || x >= W) continue;                        // wave-uniform
-    const int64_t pix = img + (int64_t)y * W + x;
-    const float* cqp = jk_sm + ((py + r) * WT + (px + r)) * JK_LD;
-    float4 cq[KEY_DIM / 4];
+  // Two pixels per round (pxl and pxl + 8: same column, next row pair) so that their dependent chains -- LDS reads, dot products, two
+  // cross-lane reductions, exponentials -- interleave; the second reduction carries (sum e, sum e*spatial) together:
+  //   K = e*sp / sum(e) / max(sum(e*sp) / sum(e), 1e-7)  -- evaluated exactly in that order (upsamplers.py:257-262).
+  for (int pp = 0; pp < 8; ++pp) {
+    float val[2][2]; int64_t pixi[2]; bool live[2];
 #pragma unroll
-    for (int k = 0; k < KEY_DIM / 4; ++k) cq[k] = *reinterpret_cast<const float4*>(cqp + 4 * k);
-    float val[2];
+    for (int e = 0; e < 2; ++e) {
+      const int pxl = wave * 16 + pp + 8 * e, py = pxl >> 3, px = pxl & 7;
+      const int y = ty0 + py, x = tx0 + px;
+      live[e] = y < H && x < W;                                // wave-uniform
+      pixi[e] = img + (int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1);
+      const float* cqp = jk_sm + ((py + r) * WT + (px + r)) * JK_LD;
+      float4 cq[KEY_DIM / 4];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      val[s2] = -INFINITY;
-      if (tv[s2]) {
-        const float* q = jk_sm + (py * WT + px + toff[s2]) * JK_LD;
-        float dot = 0.f;
+      for (int k = 0; k < KEY_DIM / 4; ++k) cq[k] = *reinterpret_cast<const float4*>(cqp + 4 * k);
 #pragma unroll
-        for (int k = 0; k < KEY_DIM / 4; ++k) {
-          const float4 v = *reinterpret_cast<const float4*>(q + 4 * k);
-          dot += v.x * cq[k].x + v.y * cq[k].y + v.z * cq[k].z + v.w * cq[k].w;
+      for (int s2 = 0; s2 < 2; ++s2) {
+        val[e][s2] = -INFINITY;
+        if (tv[s2]) {
+          const float* q = jk_sm + (py * WT + px + toff[s2]) * JK_LD;
+          float dot = 0.f;
+#pragma unroll
+          for (int k = 0; k < KEY_DIM / 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(q + 4 * k);
+            dot += v.x * cq[k].x + v.y * cq[k].y + v.z * cq[k].z + v.w * cq[k].w;
+          }
+          val[e][s2] = temp * dot;
         }
-        val[s2] = temp * dot;
       }
     }
-    const float mx = wave_max(fmaxf(val[0], val[1]));
-    float e0 = expf(val[0] - mx), e1 = expf(val[1] - mx);          // exp(-inf) = 0 for the unused lanes
-    const float inv = 1.0f / wave_sum(e0 + e1);
-    e0 = e0 * inv * sp[0]; e1 = e1 * inv * sp[1];
-    const float nrm = fmaxf(wave_sum(e0 + e1), 1e-7f);
-    float* xr = X + pix * ldx;
-    if (lane < d2) xr[lane] = e0 / nrm;
-    if (lane + 64 < d2) xr[lane + 64] = e1 / nrm;
-    if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
-    if (X16) {
-      bf16_t* x16 = X16 + pix * ldx16;
-      for (int t = lane; t < ldx16; t += 64) {
-        float v = 0.f;
-        if (t < d2) v = (t < 64 ? e0 : e1) / nrm;
-        else if (t < d2 + 3) v = gs[pix * 3 + (t - d2)];
-        x16[t] = f2bf(v);
+    float mx[2] = {fmaxf(val[0][0], val[0][1]), fmaxf(val[1][0], val[1][1])};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], o, 64)); mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], o, 64)); }
+    float ex[2][2], s1[2], s2v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      ex[e][0] = expf(val[e][0] - mx[e]); ex[e][1] = expf(val[e][1] - mx[e]);          // exp(-inf) = 0 for the unused lanes
+      s1[e] = ex[e][0] + ex[e][1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1[0] += __shfl_xor(s1[0], o, 64); s1[1] += __shfl_xor(s1[1], o, 64); }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float inv = 1.0f / s1[e];
+      ex[e][0] = ex[e][0] * inv * sp[0]; ex[e][1] = ex[e][1] * inv * sp[1];
+      s2v[e] = ex[e][0] + ex[e][1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s2v[0] += __shfl_xor(s2v[0], o, 64); s2v[1] += __shfl_xor(s2v[1], o, 64); }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (!live[e]) continue;
+      const float nrm = fmaxf(s2v[e], 1e-7f);
+      const float e0 = ex[e][0], e1 = ex[e][1];
+      const int64_t pix = pixi[e];
+      float* xr = X + pix * ldx;
+      if (lane < d2) xr[lane] = e0 / nrm;
+      if (lane + 64 < d2) xr[lane + 64] = e1 / nrm;
+      if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
+      if (X16) {
+        bf16_t* x16 = X16 + pix * ldx16;
+        for (int t = lane; t < ldx16; t += 64) {
+          float v = 0.f;
+          if (t < d2) v = (t < 64 ? e0 : e1) / nrm;
+          else if (t < d2 + 3) v = gs[pix * 3 + (t - d2)];
+          x16[t] = f2bf(v);
+        }
       }
     }
   }
@@ -911,18 +938,29 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
 namespace sg {
 __global__ __launch_bounds__(256) void jbu_geff_kernel(const float* __restrict__ text, const float* __restrict__ Wf, const float* __restrict__ bf01,
                                                        int C, int Q, float* __restrict__ geff, float* __restrict__ g0) {
-  const int c = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;             // thread = channel: Wf[k][c] reads are coalesced over c
+  // block = 64 channels x 4 K-quarters (one per wave): Wf[k][c] reads are coalesced over c, 8 independent partial sums per thread
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, q = blockIdx.y;
   const float* tq = text + (int64_t)q * C;
+  const int kq = (C + 3) / 4, k0 = wave * kq, k1 = k0 + kq < C ? k0 + kq : C;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    float a = 0.f;
-    for (int k = 0; k < C; ++k) a += Wf[(int64_t)k * C + c] * tq[k];         // (Wf^T T^T)[c, q]
-    geff[c * JBU_QMAX + q] = tq[c] + 0.1f * a;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += Wf[(int64_t)(k + u) * C + c] * tq[k + u];
+    }
+    for (; k < k1; ++k) a[0] += Wf[(int64_t)k * C + c] * tq[k];
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
-    float a = 0.f;
-    for (int k = threadIdx.x; k < C; k += 64) a += bf01[k] * tq[k];          // bf01 = 0.1 * bias (scaled at load)
-    a = wave_sum(a);
-    if (threadIdx.x == 0) g0[q] = a;
+  part[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (wave == 0 && c < C) geff[c * JBU_QMAX + q] = tq[c] + 0.1f * (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);   // (Wf^T T^T)[c, q]
+  if (blockIdx.x == 0 && wave == 1) {
+    float s0 = 0.f;
+    for (int k = lane; k < C; k += 64) s0 += bf01[k] * tq[k];                // bf01 = 0.1 * bias (scaled at load)
+    s0 = wave_sum(s0);
+    if (lane == 0) g0[q] = s0;
   }
 }
 // cls_logits[b, q] = (cls[b] / |cls[b]|) . T[q]     (segmentor.py:309-311)
@@ -940,63 +978,78 @@ __global__ __launch_bounds__(64) void jbu_cls_logits_kernel(const float* __restr
     if (lane == 0) out[b * JBU_QMAX + q] = d * inv;
   }
 }
-// One wave = 64 consecutive pixels, lane = pixel.  x rows are fetched coalesced (8 lanes x 16 B per pixel row piece) into a per-wave LDS
-// tile [64 px][32 ch] and read back pixel-per-lane (row stride 36 floats: conflict-free b128), so every lane walks ITS pixel's channels
-// while Geff[c][:] comes from LDS as a broadcast read -- Q running dots + |x|^2 per lane, no cross-lane reduction, and the logits of a
-// query go out as 256 contiguous bytes per wave.  LDS traffic per pixel: 2 x C x 4 B (tile) instead of C x Q x 4 B.
-constexpr int PL_LD = 36;
+// One wave = 128 consecutive pixels, a lane owns pixels `lane` and `lane + 64`.  x rows are fetched coalesced (8 lanes x 16 B per pixel
+// row piece) into a per-wave LDS tile [128 px][32 ch] and read back pixel-per-lane (row stride 36 floats: conflict-free b128), so every
+// lane walks ITS pixels' channels while Geff[c][:] comes from LDS as a broadcast read shared by both pixels -- Q running dots + |x|^2 per
+// pixel, no cross-lane reduction, and the logits of a query go out as 256 contiguous bytes per wave-instruction.
+constexpr int PL_LD = 36, PL_PPL = 2;
 template <int QP>
 __global__ __launch_bounds__(256, 2) void jbu_pixel_logits_kernel(const float* __restrict__ x, const float* __restrict__ rowdot, int slots,
-                                                               const float* __restrict__ geff, const float* __restrict__ g0,
-                                                               const float* __restrict__ clsl, float lambda, int64_t pixels, int64_t P, int C,
-                                                               int Q, float* __restrict__ logits) {
+                                                                  const float* __restrict__ geff, const float* __restrict__ g0,
+                                                                  const float* __restrict__ clsl, float lambda, int64_t pixels, int64_t P, int C,
+                                                                  int Q, float* __restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) float pl_sm[];
   float* sG = pl_sm;                                              // [C][QP]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* tile = pl_sm + (size_t)C * QP + wave * 64 * PL_LD;       // [64][PL_LD], private to the wave
+  float* tile = pl_sm + (size_t)C * QP + wave * (64 * PL_PPL) * PL_LD;   // [128][PL_LD], private to the wave
   for (int i = threadIdx.x; i < C * QP; i += 256) sG[i] = (i % QP) < Q ? geff[(i / QP) * JBU_QMAX + (i % QP)] : 0.f;
   __syncthreads();
-  const int64_t pix0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  const int64_t pix0 = ((int64_t)blockIdx.x * 4 + wave) * (64 * PL_PPL);
   if (pix0 >= pixels) return;
-  float acc[QP], nx = 0.f;
+  float acc[PL_PPL][QP], nx[PL_PPL];
 #pragma unroll
-  for (int q = 0; q < QP; ++q) acc[q] = 0.f;
+  for (int e = 0; e < PL_PPL; ++e) {
+    nx[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) acc[e][q] = 0.f;
+  }
   const int lp = lane >> 3, lc = lane & 7;                        // load role: pixel (within a group of 8) and 16-byte piece of its 128-byte row piece
   for (int c0 = 0; c0 < C; c0 += 32) {
-    float4 v[8];
+    float4 v[8 * PL_PPL];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 8 * PL_PPL; ++u) {
       int64_t pr = pix0 + u * 8 + lp;
       pr = pr < pixels ? pr : pixels - 1;
       v[u] = *reinterpret_cast<const float4*>(x + pr * C + c0 + 4 * lc);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(tile + (u * 8 + lp) * PL_LD + 4 * lc) = v[u];
+    for (int u = 0; u < 8 * PL_PPL; ++u) *reinterpret_cast<float4*>(tile + (u * 8 + lp) * PL_LD + 4 * lc) = v[u];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // LDS executes a wave's instructions in order: ordering only, no barrier
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
     for (int k = 0; k < 8; ++k) {
-      const float4 xv = *reinterpret_cast<const float4*>(tile + lane * PL_LD + 4 * k);
-      nx += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+      float4 xv[PL_PPL];
+#pragma unroll
+      for (int e = 0; e < PL_PPL; ++e) {
+        xv[e] = *reinterpret_cast<const float4*>(tile + (lane + 64 * e) * PL_LD + 4 * k);
+        nx[e] += xv[e].x * xv[e].x + xv[e].y * xv[e].y + xv[e].z * xv[e].z + xv[e].w * xv[e].w;
+      }
       const float* g = sG + (size_t)(c0 + 4 * k) * QP;            // same address on every lane: broadcast
 #pragma unroll
-      for (int q = 0; q < QP; ++q) acc[q] += xv.x * g[q] + xv.y * g[QP + q] + xv.z * g[2 * QP + q] + xv.w * g[3 * QP + q];
+      for (int q = 0; q < QP; ++q) {
+        const float g0v = g[q], g1v = g[QP + q], g2v = g[2 * QP + q], g3v = g[3 * QP + q];
+#pragma unroll
+        for (int e = 0; e < PL_PPL; ++e) acc[e][q] += xv[e].x * g0v + xv[e].y * g1v + xv[e].z * g2v + xv[e].w * g3v;
+      }
     }
     __builtin_amdgcn_wave_barrier();                              // the tile is rewritten in the next round
   }
-  const int64_t pix = pix0 + lane;
-  if (pix >= pixels) return;
-  float n2 = nx;
-  for (int sidx = 0; sidx < slots; ++sidx) n2 += rowdot[pix * slots + sidx];          // fixed order: deterministic
-  const float inv = 1.0f / sqrtf(n2);
-  const int64_t b = pix / P, pp = pix % P;
 #pragma unroll
-  for (int q = 0; q < QP; ++q)
-    if (q < Q) {
-      float v = (acc[q] + g0[q]) * inv;
-      if (clsl) v += lambda * clsl[b * JBU_QMAX + q];
-      logits[(b * Q + q) * P + pp] = v;
-    }
+  for (int e = 0; e < PL_PPL; ++e) {
+    const int64_t pix = pix0 + lane + 64 * e;
+    if (pix >= pixels) continue;
+    float n2 = nx[e];
+    for (int sidx = 0; sidx < slots; ++sidx) n2 += rowdot[pix * slots + sidx];        // fixed order: deterministic
+    const float inv = 1.0f / sqrtf(n2);
+    const int64_t b = pix / P, pp = pix % P;
+#pragma unroll
+    for (int q = 0; q < QP; ++q)
+      if (q < Q) {
+        float vv = (acc[e][q] + g0[q]) * inv;
+        if (clsl) vv += lambda * clsl[b * JBU_QMAX + q];
+        logits[(b * Q + q) * P + pp] = vv;
+      }
+  }
 }
 }  // namespace sg
 
@@ -1019,7 +1072,7 @@ extern "C" int sg_jbu_logits(sg_jbu* j, const float* source, const float* guidan
   SG_REQUIRE(pixels >= 1024 && pixels < (1ll << 31), "sg_jbu_logits: pixel count out of range");
   const float* x = nullptr;
   SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &x, s));
-  hipLaunchKernelGGL(jbu_geff_kernel, dim3((unsigned)cdiv(C, 256), (unsigned)Q), dim3(256), 0, s, text, j->fin_w, j->fin_b, C, Q, p.geff, p.g0);
+  hipLaunchKernelGGL(jbu_geff_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)Q), dim3(256), 0, s, text, j->fin_w, j->fin_b, C, Q, p.geff, p.g0);
   SG_LAUNCH_CHECK();
   const bool use_cls = cls != nullptr && cls_token_lambda != 0.f;
   if (use_cls) { hipLaunchKernelGGL(jbu_cls_logits_kernel, dim3(B), dim3(64), 0, s, cls, text, C, Q, p.clsl); SG_LAUNCH_CHECK(); }
@@ -1029,10 +1082,10 @@ extern "C" int sg_jbu_logits(sg_jbu* j, const float* source, const float* guidan
   g.rowdot = p.rowdot; g.rowdot_ld = C / 64;
   SG_TRY(gemm_bf16(g, s));
   const int slots = C / 64;
-  const unsigned grid = (unsigned)cdiv(pixels, 256);
+  const unsigned grid = (unsigned)cdiv(pixels, 4 * 64 * PL_PPL);
 #define SG_JBU_PIX(QP)                                                                                                        \
   do {                                                                                                                         \
-    const size_t lds = ((size_t)C * QP + 4 * 64 * PL_LD) * sizeof(float);                                                      \
+    const size_t lds = ((size_t)C * QP + 4 * 64 * PL_PPL * PL_LD) * sizeof(float);                                             \
     if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_pixel_logits_kernel<QP>), lds));         \
     hipLaunchKernelGGL(jbu_pixel_logits_kernel<QP>, dim3(grid), dim3(256), lds, s, x, p.rowdot, slots, p.geff, p.g0,           \
                        use_cls ? p.clsl : nullptr, cls_token_lambda, pixels, P, C, Q, logits);                                 \

@@ -21,7 +21,7 @@ DEV = "cuda:0"
 # rounding replaces a whole token) / q99 4.0e-3 / agreement >= 0.9847, sa_attn 7.7e-3;  f16: 1.1e-3, 1.2e-3, 1.06e-4 / 7.8e-5 / 1.0000, 1.0e-3
 HALF_TOL = {
     "bf16": dict(tiny_tokens=0.018, gem=0.015, real_err=0.14, real_q99=8e-3, real_agree=0.97, sa_attn=0.016),
-    "f16": dict(tiny_tokens=2.2e-3, gem=2.5e-3, real_err=2.5e-4, real_q99=1.6e-4, real_agree=0.9995, sa_attn=2.2e-3),
+    "f16": dict(tiny_tokens=2.2e-3, gem=2.5e-3, real_err=2.5e-4, real_q99=1.6e-4, real_agree=0.998, sa_attn=2.2e-3),   # agreement: 1369 samples, two flips allowed
 }
 POTSDAM_QIDX = [0, 0, 1, 2, 3, 4, 5, 5]
 SIM = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
