@@ -171,16 +171,22 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], o, 64)); mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], o, 64)); }
     float ex[2][2], s1[2], s2v[2];
+    const bool fast = X16 != nullptr;                          // throughput mode: hardware exp2 / rcp (1 ulp) -- the result is rounded to bf16 anyway
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      ex[e][0] = expf(val[e][0] - mx[e]); ex[e][1] = expf(val[e][1] - mx[e]);          // exp(-inf) = 0 for the unused lanes
+      if (fast) {
+        ex[e][0] = __builtin_amdgcn_exp2f((val[e][0] - mx[e]) * 1.4426950408889634f);
+        ex[e][1] = __builtin_amdgcn_exp2f((val[e][1] - mx[e]) * 1.4426950408889634f);
+      } else {
+        ex[e][0] = expf(val[e][0] - mx[e]); ex[e][1] = expf(val[e][1] - mx[e]);        // exp(-inf) = 0 for the unused lanes
+      }
       s1[e] = ex[e][0] + ex[e][1];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1[0] += __shfl_xor(s1[0], o, 64); s1[1] += __shfl_xor(s1[1], o, 64); }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const float inv = 1.0f / s1[e];
+      const float inv = fast ? __builtin_amdgcn_rcpf(s1[e]) : 1.0f / s1[e];
       ex[e][0] = ex[e][0] * inv * sp[0]; ex[e][1] = ex[e][1] * inv * sp[1];
       s2v[e] = ex[e][0] + ex[e][1];
     }
@@ -190,20 +196,19 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
     for (int e = 0; e < 2; ++e) {
       if (!live[e]) continue;
       const float nrm = fmaxf(s2v[e], 1e-7f);
-      const float e0 = ex[e][0], e1 = ex[e][1];
       const int64_t pix = pixi[e];
       float* xr = X + pix * ldx;
-      if (lane < d2) xr[lane] = e0 / nrm;
-      if (lane + 64 < d2) xr[lane + 64] = e1 / nrm;
+      float k0, k1;
+      if (fast) { const float rn = __builtin_amdgcn_rcpf(nrm); k0 = ex[e][0] * rn; k1 = ex[e][1] * rn; }
+      else { k0 = ex[e][0] / nrm; k1 = ex[e][1] / nrm; }
+      if (lane < d2) xr[lane] = k0;
+      if (lane + 64 < d2) xr[lane + 64] = k1;
       if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
-      if (X16) {
+      if (X16) {                                               // [taps | guidance | zero padding] as the bf16 A operand of the fixup GEMM
         bf16_t* x16 = X16 + pix * ldx16;
-        for (int t = lane; t < ldx16; t += 64) {
-          float v = 0.f;
-          if (t < d2) v = (t < 64 ? e0 : e1) / nrm;
-          else if (t < d2 + 3) v = gs[pix * 3 + (t - d2)];
-          x16[t] = f2bf(v);
-        }
+        if (lane < ldx16) x16[lane] = f2bf(lane < d2 ? k0 : (lane < d2 + 3 ? gs[pix * 3 + (lane - d2)] : 0.f));
+        const int t2 = lane + 64;
+        if (t2 < ldx16) x16[t2] = f2bf(t2 < d2 ? k1 : (t2 < d2 + 3 ? gs[pix * 3 + (t2 - d2)] : 0.f));
       }
     }
   }
