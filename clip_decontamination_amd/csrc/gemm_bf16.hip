@@ -786,7 +786,11 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
     for (int ps = 0; ps < NPASS; ++ps) {
       int m = rb + ps * RPPF + lane / LPRF; m = m < a.M ? m : a.M - 1;
       int n = col0 + (lane % LPRF) * 4; n = n < a.N ? n : a.N - 4;
-      dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
+      if (a.rowdot && a.rowdot_res_bf16) {               // the JBU tail keeps x in bf16 only (wave-uniform branch)
+        const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(res) + (int64_t)m * a.ldr + n);
+        dst[ps] = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                              __uint_as_float(raw.y & 0xffff0000u));
+      } else dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
     }
   };
   const bool pipe_res = res != nullptr && !c_bf16;

@@ -804,7 +804,7 @@ extern "C" size_t sg_jbu_workspace_bytes(const sg_jbu* j, int B, int gh, int gw)
 // The four 2x stages (JBULearnedRange.forward x 4): source [B, gh*gw, C] -> *x_out [B, 16gh*16gw, C] f32 inside the workspace
 // (and its bf16 copy in p.x16 in throughput mode when C % 64 == 0)
 static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
-                      const JbuPlan& p, const float** x_out, hipStream_t s) {
+                      const JbuPlan& p, const float** x_out, hipStream_t s, bool want_f32_x = true) {
   const int C = j->C;
   const float* src = source;
   int h = gh, w = gw;
@@ -867,7 +867,7 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
       bf16_t* s16 = stg == 0 ? tok16 : o16[stg - 1];
       if (stg == 0) SG_TRY(pack_rows(source, (int64_t)B * gh * gw, C, C, tok16, C, 1, s));
       bf16_t* d16 = stg == 3 ? (bf16_t*)p.x16 : o16[stg];
-      float* d32 = stg == 3 ? dst : nullptr;
+      float* d32 = (stg == 3 && want_f32_x) ? dst : nullptr;   // the fused tail works from the bf16 copy alone: 4 B per element not written
       dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
       if (r == 5) {
         SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_kernel<5>), LowCfg<5>::LDS));
@@ -988,8 +988,8 @@ __global__ __launch_bounds__(64) void jbu_cls_logits_kernel(const float* __restr
 // lane walks ITS pixels' channels while Geff[c][:] comes from LDS as a broadcast read shared by both pixels -- Q running dots + |x|^2 per
 // pixel, no cross-lane reduction, and the logits of a query go out as 256 contiguous bytes per wave-instruction.
 constexpr int PL_LD = 36, PL_PPL = 2;
-template <int QP>
-__global__ __launch_bounds__(256, 2) void jbu_pixel_logits_kernel(const float* __restrict__ x, const float* __restrict__ rowdot, int slots,
+template <int QP, typename XT>
+__global__ __launch_bounds__(256, 2) void jbu_pixel_logits_kernel(const XT* __restrict__ x, const float* __restrict__ rowdot, int slots,
                                                                   const float* __restrict__ geff, const float* __restrict__ g0,
                                                                   const float* __restrict__ clsl, float lambda, int64_t pixels, int64_t P, int C,
                                                                   int Q, float* __restrict__ logits) {
@@ -1015,7 +1015,12 @@ __global__ __launch_bounds__(256, 2) void jbu_pixel_logits_kernel(const float* _
     for (int u = 0; u < 8 * PL_PPL; ++u) {
       int64_t pr = pix0 + u * 8 + lp;
       pr = pr < pixels ? pr : pixels - 1;
-      v[u] = *reinterpret_cast<const float4*>(x + pr * C + c0 + 4 * lc);
+      if constexpr (sizeof(XT) == 4) v[u] = *reinterpret_cast<const float4*>(x + pr * C + c0 + 4 * lc);
+      else {                                                      // bf16 rows (the throughput tail keeps x in bf16 only)
+        const uint2 raw = *reinterpret_cast<const uint2*>(x + pr * C + c0 + 4 * lc);
+        v[u] = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                           __uint_as_float(raw.y & 0xffff0000u));
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8 * PL_PPL; ++u) *reinterpret_cast<float4*>(tile + (u * 8 + lp) * PL_LD + 4 * lc) = v[u];
@@ -1076,23 +1081,24 @@ extern "C" int sg_jbu_logits(sg_jbu* j, const float* source, const float* guidan
   const int64_t P = (int64_t)16 * gh * 16 * gw, pixels = (int64_t)B * P;
   SG_REQUIRE(pixels >= 1024 && pixels < (1ll << 31), "sg_jbu_logits: pixel count out of range");
   const float* x = nullptr;
-  SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &x, s));
+  SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &x, s, /*want_f32_x=*/false));
+  const bf16_t* x16 = (const bf16_t*)p.x16;                 // the 16x features exist in bf16 only: the conv's 4 B/element f32 store and its two re-reads are gone
   hipLaunchKernelGGL(jbu_geff_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)Q), dim3(256), 0, s, text, j->fin_w, j->fin_b, C, Q, p.geff, p.g0);
   SG_LAUNCH_CHECK();
   const bool use_cls = cls != nullptr && cls_token_lambda != 0.f;
   if (use_cls) { hipLaunchKernelGGL(jbu_cls_logits_kernel, dim3(B), dim3(64), 0, s, cls, text, C, Q, p.clsl); SG_LAUNCH_CHECK(); }
   GemmBf16Args g{};
-  g.A = (const bf16_t*)p.x16; g.lda = C; g.W = (const bf16_t*)j->fin_w16; g.ldw = C; g.bias = j->fin_b; g.residual = x; g.ldr = C;
+  g.A = x16; g.lda = C; g.W = (const bf16_t*)j->fin_w16; g.ldw = C; g.bias = j->fin_b; g.residual = (const float*)x16; g.ldr = C;
   g.C = p.rowdot; g.ldc = C; g.c_is_bf16 = 0; g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.act = 0; g.alpha = 0.1f;
-  g.rowdot = p.rowdot; g.rowdot_ld = C / 64;
+  g.rowdot = p.rowdot; g.rowdot_ld = C / 64; g.rowdot_res_bf16 = 1;
   SG_TRY(gemm_bf16(g, s));
   const int slots = C / 64;
   const unsigned grid = (unsigned)cdiv(pixels, 4 * 64 * PL_PPL);
 #define SG_JBU_PIX(QP)                                                                                                        \
   do {                                                                                                                         \
     const size_t lds = ((size_t)C * QP + 4 * 64 * PL_PPL * PL_LD) * sizeof(float);                                             \
-    if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_pixel_logits_kernel<QP>), lds));         \
-    hipLaunchKernelGGL(jbu_pixel_logits_kernel<QP>, dim3(grid), dim3(256), lds, s, x, p.rowdot, slots, p.geff, p.g0,           \
+    if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_pixel_logits_kernel<QP, bf16_t>), lds)); \
+    hipLaunchKernelGGL((jbu_pixel_logits_kernel<QP, bf16_t>), dim3(grid), dim3(256), lds, s, x16, p.rowdot, slots, p.geff, p.g0,  \
                        use_cls ? p.clsl : nullptr, cls_token_lambda, pixels, P, C, Q, logits);                                 \
   } while (0)
   if (Q <= 8) SG_JBU_PIX(8); else if (Q <= 16) SG_JBU_PIX(16); else SG_JBU_PIX(32);

@@ -10,7 +10,7 @@ ROOT=$PWD
 export TMPDIR=/tmp
 mkdir -p $OUT
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fp8 -o b -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --precision fp8 > $OUT/bench_fp8.json 2> $OUT/fp8.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fp8 -o b -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-self-check --precision fp8 > $OUT/bench_fp8.json 2> $OUT/fp8.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/jbu -o j -- python3 $ROOT/tools/bench_jbu.py ViT-B/16 > $OUT/jbu.log 2> $OUT/jbu.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/jbu_fetch -o f -- python3 $ROOT/tools/bench_jbu.py ViT-B/16 > $OUT/jbu_fetch.log 2> $OUT/jbu_fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/jbu_write -o w -- python3 $ROOT/tools/bench_jbu.py ViT-B/16 > $OUT/jbu_write.log 2> $OUT/jbu_write.err
