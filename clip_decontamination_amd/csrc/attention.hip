@@ -178,24 +178,12 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
     const float bias_rn = (GENERIC && a.bias_rn) ? a.bias_rn[((int64_t)b * a.H + hd) * a.N + q_ld] : 1.f;
     auto fetch_bias = [&](int kbase) {
       if (GENERIC && a.bias) {
-        // the element-type switch sits OUTSIDE the 32-element loop: inside it, every iteration becomes a basic block of its own and the
-        // loads are no longer issued back to back (measured: 5.2 -> 16.9 ms per launch of the 'Experimental' last block)
-        if (a.bias_kind == HK_F32) {
 #pragma unroll
-          for (int i = 0; i < 32; ++i) {
-            const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-            float bvv = (key >= 1 && key < a.N && q_ld >= 1) ? a.bias[(int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1)] : 0.f;
-            if (a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
-            bnext[i] = bvv;
-          }
-        } else {
-          // 2-byte map: keep the RAW bits (converting here would make every load wait for its data inside this prefetch loop); converted at use
-          const bf16_t* b16 = reinterpret_cast<const bf16_t*>(a.bias);
-#pragma unroll
-          for (int i = 0; i < 32; ++i) {
-            const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-            bnext[i] = __uint_as_float((key >= 1 && key < a.N && q_ld >= 1) ? (uint32_t)b16[(int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1)] : 0u);
-          }
+        for (int i = 0; i < 32; ++i) {
+          const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
+          float bvv = (key >= 1 && key < a.N && q_ld >= 1) ? a.bias[(int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1)] : 0.f;
+          if (a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
+          bnext[i] = bvv;
         }
       }
     };
@@ -254,15 +242,6 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
       float sc[32];
       float mloc;
       if (GENERIC) {
-        if (a.bias && a.bias_kind != HK_F32) {             // 2-byte map: decode the prefetched raw bits in place (branch outside the loops)
-          if (a.bias_kind == HK_F16) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) bnext[i] = h2f(f16_t{(uint16_t)__float_as_uint(bnext[i])});
-          } else {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) bnext[i] = __uint_as_float(__float_as_uint(bnext[i]) << 16);
-          }
-        }
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = k0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;

@@ -140,7 +140,7 @@ struct AttnSpec {
   const void* v; int64_t v_sb, v_st;
   int n_terms, sum_scores, resoftmax, causal;
   float scale; const float* scale_per_image;
-  const float* bias; float bias_w; int64_t bias_bstride; const float* bias_rn; const float* bias_cn; int bias_kind;
+  const float* bias; float bias_w; int64_t bias_bstride; const float* bias_rn; const float* bias_cn;
   float out_scale;
   void* ctx; int64_t ctx_sb, ctx_st;
   bool want_lse;
@@ -159,7 +159,7 @@ static int attn_generic(int bf16, const AttnSpec& sp, int B, int N, int H, int d
       SG_TRY(attention_bf16(p, s));
       a.resoftmax = 1; a.lse_in = buf.lse1;
     }
-    a.bias = sp.bias; a.bias_w = sp.bias_w; a.bias_bstride = sp.bias_bstride; a.bias_rn = sp.bias_rn; a.bias_cn = sp.bias_cn; a.bias_kind = sp.bias_kind; a.ctx = (bf16_t*)sp.ctx; a.lse_out = sp.want_lse ? buf.lse : nullptr;
+    a.bias = sp.bias; a.bias_w = sp.bias_w; a.bias_bstride = sp.bias_bstride; a.bias_rn = sp.bias_rn; a.bias_cn = sp.bias_cn; a.ctx = (bf16_t*)sp.ctx; a.lse_out = sp.want_lse ? buf.lse : nullptr;
     return attention_bf16(a, s);
   }
   const int64_t NN = (int64_t)N * N;
@@ -194,8 +194,7 @@ static int attn_generic(int bf16, const AttnSpec& sp, int B, int N, int H, int d
 
 // Attention over packed qkv [B,N,3D] (compute dtype) -> ctx [B,N,D] (compute dtype).
 static int run_attention(int bf16, const void* qkv, int B, int N, int D, int H, int model_type, const float* sim, float sim_w,
-                         const float* scale_per_image, void* ctx, bool want_lse, const AttnBuffers& buf, hipStream_t s, bool causal = false,
-                         int sim_kind = HK_F32) {
+                         const float* scale_per_image, void* ctx, bool want_lse, const AttnBuffers& buf, hipStream_t s, bool causal = false) {
   const int dh = D / H;
   Variant v;
   if (!variant_of(model_type, v)) return fail(SG_ERR_INVALID, "attention variant %d is not built (NACLIP / NOnly / GAV: SURVEY.md §8f rank 3)", model_type);
@@ -206,13 +205,13 @@ static int run_attention(int bf16, const void* qkv, int B, int N, int D, int H, 
   sp.st = sp.v_st = 3 * (int64_t)D; sp.sb = sp.v_sb = (int64_t)N * 3 * D;
   sp.n_terms = v.n_terms; sp.sum_scores = v.sum_scores; sp.resoftmax = v.resoftmax; sp.causal = causal ? 1 : 0;
   sp.scale = v.scale_mul / sqrtf((float)dh); sp.scale_per_image = scale_per_image;
-  sp.bias = sim; sp.bias_w = sim_w; sp.bias_bstride = (int64_t)(N - 1) * (N - 1); sp.out_scale = 1.f; sp.bias_kind = sim_kind;
+  sp.bias = sim; sp.bias_w = sim_w; sp.bias_bstride = (int64_t)(N - 1) * (N - 1); sp.out_scale = 1.f;
   if (v.gauss) {
     const int gside = (int)lroundf(sqrtf((float)(N - 1)));                 // the reference assumes a square grid here (transformer.py:912)
     SG_REQUIRE(gside * gside == N - 1, "Gaussian-window attention needs a square patch grid (N-1 = %d)", N - 1);
     SG_REQUIRE(buf.omega && buf.qnorm && buf.knorm, "Gaussian-window attention: scratch missing");
     SG_TRY(gaussian_bias(gside, gside, 1.0f, buf.omega, s));
-    sp.bias = buf.omega; sp.bias_bstride = 0; sp.bias_w = 1.f; sp.bias_kind = HK_F32;
+    sp.bias = buf.omega; sp.bias_bstride = 0; sp.bias_w = 1.f;
     if (v.gauss == 2) {
       SG_TRY(head_norms(sp.q[0], bf16, sp.sb, sp.st, B, N, H, dh, buf.qnorm, s));
       SG_TRY(head_norms(sp.k[0], bf16, sp.sb, sp.st, B, N, H, dh, buf.knorm, s));
@@ -249,11 +248,9 @@ static int linear_fp8(const uint8_t* A8, const float* sa, int64_t lda, const uin
   return gemm_bf16(g, s);
 }
 
-__global__ void zero_diag_kernel(float* sim, int n, int64_t total, int half) {
+__global__ void zero_diag_kernel(float* sim, int n, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int64_t at = (i / n) * (int64_t)n * n + (i % n) * (int64_t)(n + 1);
-  if (half) reinterpret_cast<bf16_t*>(sim)[at] = 0; else sim[at] = 0.f;          // +0.0 has the same bits in bf16 and f16
+  if (i < total) sim[(i / n) * (int64_t)n * n + (i % n) * (int64_t)(n + 1)] = 0.f;
 }
 __global__ void unpack_bf16_kernel(const bf16_t* src, float* dst, int64_t n, int f16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,13 +258,11 @@ __global__ void unpack_bf16_kernel(const bf16_t* src, float* dst, int64_t n, int
 }
 
 // similarity map from L2-normalised patch rows xhat [B,n,D] (compute dtype) -> sim [B,n,n] f32
-// sim_half: keep the map in the operand type (bf16 / f16) instead of f32 -- the tower's own map, read back only by the fused attention
-static int similarity_from_xhat(int bf16, const void* xhat, int B, int n, int D, float temperature, int add_self, float* sim, hipStream_t s,
-                                bool sim_half = false) {
+static int similarity_from_xhat(int bf16, const void* xhat, int B, int n, int D, float temperature, int add_self, float* sim, hipStream_t s) {
   if (bf16) {
     GemmBf16Args g{};
     g.A = (const bf16_t*)xhat; g.lda = D; g.strideA = (int64_t)n * D; g.W = (const bf16_t*)xhat; g.ldw = D; g.strideW = (int64_t)n * D;
-    g.C = sim; g.ldc = n; g.strideC = (int64_t)n * n; g.c_is_bf16 = sim_half ? 1 : 0; g.M = n; g.N = n; g.K = D; g.batch = B; g.act = 0;
+    g.C = sim; g.ldc = n; g.strideC = (int64_t)n * n; g.c_is_bf16 = 0; g.M = n; g.N = n; g.K = D; g.batch = B; g.act = 0;
     g.alpha = 1.0f / temperature; g.f16 = bf16 == HK_F16;
     SG_TRY(gemm_bf16(g, s));
   } else {
@@ -278,7 +273,7 @@ static int similarity_from_xhat(int bf16, const void* xhat, int B, int n, int D,
   }
   if (!add_self) {
     const int64_t total = (int64_t)B * n;
-    hipLaunchKernelGGL(zero_diag_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, sim, n, total, (bf16 && sim_half) ? 1 : 0);
+    hipLaunchKernelGGL(zero_diag_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, sim, n, total);
     SG_LAUNCH_CHECK();
   }
   return SG_OK;
@@ -685,9 +680,9 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
       }
     }
     if (o->similarity_enabled)
-      // the map stays f32 (similarity_enhancement.py computes it in fp32): a 2-byte map (sim_half, bias_kind of the attention kernel) halves
-      // the bias fetch but measured no faster -- the 'Experimental' kernel is bound by its two exponentials per score, not by the fetch
-      SG_TRY(similarity_from_xhat(c->hk, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s, false));
+      // the map stays f32 (similarity_enhancement.py computes it in fp32): a 2-byte map halves the attention kernel's bias fetch but was
+      // measured no faster (round 2) -- the 'Experimental' kernel is bound by its two exponentials per score, not by the fetch
+      SG_TRY(similarity_from_xhat(c->hk, p.xhat, B, n, D, o->similarity_temperature, o->similarity_add_self, p.sim, s));
     // ---- last block: self-self attention on ln_1(x), no residual / MLP when ignore_residual (transformer.py:627-643) ----
     const LayerW& LL = c->layers[L - 1];
     AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1, p.omega, p.qnorm, p.knorm};
@@ -705,7 +700,7 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     const void* ctx = p.ctx; int64_t ctx_ld = D;
     if (o->model_type == SG_MASKCLIP) { ctx = (const char*)p.qkv + (size_t)2 * D * c->esz; ctx_ld = 3 * D; }   // identity attention: ctx = v
     else SG_TRY(run_attention(c->hk, p.qkv, B, N, D, H, o->model_type, (o->similarity_enabled && o->model_type < SG_NACLIP) ? p.sim : nullptr, o->similarity_weight,
-                              nullptr, p.ctx, false, ab, s, false, HK_F32));
+                              nullptr, p.ctx, false, ab, s));
     SG_TRY(linear(c->hk, ctx, ctx_ld, LL.w_out, LL.b_out, o->ignore_residual ? nullptr : p.x, p.out_last, D, true, (int)R, D, D, ACT_NONE, s));
     if (!o->ignore_residual) SG_TRY(mlp_block(c, LL, p.out_last, p, R, s));
     // ---- attention-map layer fusion: mask the fused map's outlier columns, renormalise, re-weight every token (transformer.py:647-690) ----

@@ -41,7 +41,6 @@ struct AttnArgs {
   float scale; const float* scale_per_image;  // per-image scale overrides `scale` when non-null (GEM inv_temp)
   const float* bias; float bias_w;          // [B, N-1, N-1] symmetric, or null; batch stride bias_bstride (0 = shared by all images)
   int64_t bias_bstride;
-  int bias_kind;                            // element type of `bias`: 0 = f32, 1 = bf16, 2 = f16 (the tower keeps its similarity map in the operand type: half the bytes per head)
   const float* bias_rn; const float* bias_cn; // optional [B,H,N] row / column factors of the bias (NOnly / GAV: |q_i|, |k_j|)
   int causal;                               // keys after the query are masked (CLIP text tower)
   int resoftmax;                            // 'Experimental': softmax(softmax(score) + bias_w*bias); needs lse_in
