@@ -158,7 +158,11 @@ struct GemmBf16Args {
   // rowdot[m * rowdot_ld + n / 64] = sum over the 64 columns [n, n + 64) of v * (2 r + v)  (= |r + v|^2 - |r|^2 of that column slice):
   // the JBU tail needs only the norm of x + 0.1 * conv1x1(x), never the C x S^2 map itself.  f32 residual required.
   float* rowdot; int64_t rowdot_ld;
-  int rowdot_res_bf16;                                // row-dot mode: `residual` points to bf16 (same ldr, in elements) instead of f32
+  int rowdot_res_bf16;
+  // persistent kernel only: W-panel-resident tile order.  ngroup > 0: every XCD owns a block of M tiles and walks them N-group by
+  // N-group (ngroup N tiles at a time, chosen so that their W panels fit the XCD's 4 MiB L2 next to the streaming A panels):
+  // the W panels are fetched once per XCD instead of once per round of workgroups.  0 = raster order in XCD chunks.
+  int ngroup;                                // row-dot mode: `residual` points to bf16 (same ldr, in elements) instead of f32
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
 void set_gemm_config(int c);   // tuning hook (per calling thread): -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants

@@ -748,6 +748,7 @@ static int launch_pp32(const GemmBf16Args& a, hipStream_t s) {
   return SG_OK;
 }
 
+static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gemm_config(1000 + v)): -1 automatic N-group size, 0 raster order, v > 0 forced N-group size
 // ---- persistent ping-pong: the production kernel for the large ViT linears ---------------------------------------------------------
 // gemm_bf16_pp32's ring (K tile 32, four slots) with three changes measured to matter:
 //   * ONE phase of 32 MFMAs per K tile (12 ds_read_b128 + 4 global_load_lds per wave per READ segment): the barrier + LDS-latency
@@ -875,18 +876,33 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
   const bf16_t* A = a.A + (int64_t)z * a.strideA;
   const bf16_t* W = a.W + (int64_t)z * a.strideW;
   const int nt = a.K / KT32;
-  const int my_tiles = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // tile order (a.ngroup > 0): XCD x = blockIdx.x & 7 owns M tiles [mlo, mlo + mcnt) and walks its mcnt * tiles_n tiles N-group by N-group
+  const int NG = a.ngroup;
+  const int wpx = (int)gridDim.x >> 3, wx = (int)blockIdx.x >> 3, xc = (int)blockIdx.x & 7;
+  const int mq8 = tiles_m >> 3, mr8 = tiles_m & 7;
+  const int mlo = xc * mq8 + (xc < mr8 ? xc : mr8), mcnt = mq8 + (xc < mr8 ? 1 : 0), xcnt = mcnt * tiles_n;
+  const int my_tiles = NG > 0 ? (xcnt - wx + wpx - 1) / wpx : (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_tiles * nt;                          // length of this workgroup's K-tile stream
 
   const int srow = lane >> 2, cpos = lane & 3;
   struct Src { const bf16_t* a[2]; const bf16_t* w[2]; int m0, n0; };
   auto make_src = [&](int j) {
     Src sp;
-    const int v = (int)blockIdx.x + j * (int)gridDim.x;      // virtual id; XCD x = v & 7 walks a contiguous chunk of tile ids
-    const int xcd = v & 7, seq = v >> 3;
-    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
-    tile = tile < nwg ? tile : nwg - 1;
-    sp.m0 = (tile / tiles_n) * PBM; sp.n0 = (tile % tiles_n) * PBN;
+    if (NG > 0) {
+      int Lx = wx + j * wpx;                                   // index inside this XCD's tile set
+      Lx = Lx < xcnt ? Lx : xcnt - 1;
+      const int gsz = mcnt * NG, ngroups = (tiles_n + NG - 1) / NG;
+      int grp = Lx / gsz; grp = grp < ngroups - 1 ? grp : ngroups - 1;
+      const int rem = Lx - grp * gsz;
+      const int ncols = grp == ngroups - 1 ? tiles_n - grp * NG : NG;
+      sp.m0 = (mlo + rem / ncols) * PBM; sp.n0 = (grp * NG + rem % ncols) * PBN;
+    } else {
+      const int v = (int)blockIdx.x + j * (int)gridDim.x;    // virtual id; XCD x = v & 7 walks a contiguous chunk of tile ids
+      const int xcd = v & 7, seq = v >> 3;
+      int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+      tile = tile < nwg ? tile : nwg - 1;
+      sp.m0 = (tile / tiles_n) * PBM; sp.n0 = (tile % tiles_n) * PBN;
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int ra = 128 * g + 32 * wi + 16 * p + srow;
@@ -995,12 +1011,25 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
   const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
-  hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, a, a.act, a.c_is_bf16);
+  GemmBf16Args b = a;
+  // W-panel-resident order where it pays: more N tiles than fit the L2 together and a short K (re-reading the A panels once per
+  // N-group must cost less than re-streaming every W panel once per round): the K = 1024 linears with N = 3072 / 4096
+  const int64_t tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, 256);
+  const int64_t panel = (int64_t)256 * a.K * 2;
+  b.ngroup = 0;
+  if (g_gemm_order != 0 && a.batch == 1 && grid == (unsigned)n_cu && n_cu % 8 == 0 && (tiles_m / 8) * tiles_n >= n_cu / 8 && a.K <= 2048) {
+    const int ng = (int)((2 << 20) / panel);
+    if (ng >= 1 && tiles_n > ng) b.ngroup = g_gemm_order > 0 ? g_gemm_order : ng;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.batch), dim3(512), lds, s, b, a.act, a.c_is_bf16);
   return SG_OK;
 }
 
 static thread_local int g_gemm_config = -1;                // -1 = pick per shape (tuning override, per calling thread)
-void set_gemm_config(int c) { g_gemm_config = c; }
+void set_gemm_config(int c) {
+  if (c >= 1000) { g_gemm_order = c - 1001; return; }      // 1000 -> -1 (automatic), 1001 -> 0 (raster), 1001 + v -> N-group size v
+  g_gemm_config = c;
+}
 
 
 template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false>

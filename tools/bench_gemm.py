@@ -10,6 +10,9 @@ dev = "cuda:0"
 M = int(os.environ.get("GEMM_TILES", "32")) * 1370
 SHAPES = [("qkv", M, 3072, 1024, 0, 1), ("out", M, 1024, 1024, 0, 0), ("fc", M, 4096, 1024, 1, 1), ("proj", M, 1024, 4096, 0, 0)]
 CONFIGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6".split(","))]
+# tile order of the persistent kernel (config 30): GEMM_ORDER = auto | raster | <N-group size>
+_order = os.environ.get("GEMM_ORDER", "auto")
+lib.sg_set_gemm_config(1000 if _order == "auto" else (1001 if _order == "raster" else 1001 + int(_order)))
 ROUNDS, ITERS = 5, 10
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
