@@ -764,7 +764,7 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 //        A(s+2), W(s+2), A(s+3) = 6), group 1 after READ(s) (tiles s+2, s+3 = 8); both before the barrier closing slot 2s+1.
 //   tile end: group 0 takes one extra barrier (both groups are then past every read of the tile's last K tile), every wave runs the
 //        coalescing epilogue through a private patch inside the just-consumed ring slot, one barrier, group 1 re-staggers.
-template <int MI, int NI, bool F16>
+template <int MI, int NI, bool F16, bool SCALED = false>
 __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
                                                 int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
@@ -799,13 +799,29 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
 #pragma unroll
     for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
   }
+  float4 cs4[NI];                                          // SCALED (fp8): per-output-channel scales of this lane's columns
+  if constexpr (SCALED) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = col0 + j * 16 + (lane >> 4) * 4;
+      cs4[j] = n + 3 < a.N ? *reinterpret_cast<const float4*>(a.col_scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float4 v4[NI];
+    float al = a.alpha;
+    if constexpr (SCALED) { int m = row0 + i * 16 + (lane & 15); m = m < a.M ? m : a.M - 1; al *= a.row_scale[m]; }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      float v[4] = {acc[i][j][0] * a.alpha + bias4[j].x, acc[i][j][1] * a.alpha + bias4[j].y, acc[i][j][2] * a.alpha + bias4[j].z,
-                    acc[i][j][3] * a.alpha + bias4[j].w};
+      float v[4];
+      if constexpr (SCALED) {
+        v[0] = acc[i][j][0] * (al * cs4[j].x) + bias4[j].x; v[1] = acc[i][j][1] * (al * cs4[j].y) + bias4[j].y;
+        v[2] = acc[i][j][2] * (al * cs4[j].z) + bias4[j].z; v[3] = acc[i][j][3] * (al * cs4[j].w) + bias4[j].w;
+      } else {
+        v[0] = acc[i][j][0] * al + bias4[j].x; v[1] = acc[i][j][1] * al + bias4[j].y;
+        v[2] = acc[i][j][2] * al + bias4[j].z; v[3] = acc[i][j][3] * al + bias4[j].w;
+      }
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -1003,6 +1019,174 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 #undef SG_PS_SYNC
 }
 
+
+// ---- persistent fp8 ping-pong (SG_PREC_FP8: the QKV / fc / proj linears of the ordinary blocks) ------------------------------------
+// The bf16 persistent kernel's structure carried to OCP e4m3 operands: 256 x 256 output tile, 8 waves in two groups that alternate READ /
+// MFMA segments, persistent workgroups whose K-step stream runs across output tiles, epilogue through a per-wave LDS patch.
+// A K step is 128 fp8 per row = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 output (32 cycles: twice the bf16 form at 4x the K).
+// An operand fragment is 32 B per lane, so the 12 fragments of a wave (8 A + 4 W) no longer fit next to 128 accumulators: a K step is
+// TWO phases (rows 0-63 / 64-127 of the group's half), the 4 W fragments stay in registers across both.
+//   slots (barrier intervals), group 0: READ0(s) = 4s, MFMA0(s) = 4s+1, READ1(s) = 4s+2, MFMA1(s) = 4s+3; group 1 one later.
+// LDS, all 160 KiB: the A ring has 2 slots, the W ring 3 (32 KiB each: 256 rows x 128 B, 16-byte chunks XOR-swizzled as in the 128-byte
+// bf16 image).  A-half g is only ever read by group g, so two slots suffice; W is read by both groups, which costs it one more slot:
+//   loads : READ0(t): group g issues A_g(t+1)                    (position (t+1)&1, last read in READ1(t-1), retired at slot 4t-1+g)
+//           READ1(t): group 0 issues its rows of W(t+2), group 1 its rows of W(t+3)
+//             (W(t) is read in READ0(t) = slots 4t / 4t+1 and retired when slot 4t+2 opens: group 1 (slot 4t+3) may overwrite it, group 0
+//              (slot 4t+2) may not yet and refills the position of W(t-1) instead)
+//   RAW   : every wave ends MFMA1(t) with vmcnt(4): everything but the W pieces it issued in READ1(t) has landed -- its A(t+1) pieces and
+//           its pieces of W(t+1) (issued one or two steps earlier) -- before the barrier that precedes READ0(t+1).
+//   tile end: as in the bf16 kernel (group 0 takes one extra barrier, epilogue through a patch inside the just-consumed A slot, barrier,
+//           group 1 re-staggers).  Look-ahead is at most 3 K steps, so K >= 512 (4 steps per tile) keeps loads within the next tile.
+template <bool DUMMY = false>
+__global__ __launch_bounds__(512) void gemm_fp8_persist(GemmBf16Args a, int act, int c_bf16) {
+  constexpr int PBM = 256, PBN = 256, KB = 128;                          // K step in bytes (= fp8 elements)
+  constexpr int SLOT = 256 * KB;                                         // 32 KiB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ldsA = lds;                                                      // 2 slots
+  char* ldsW = lds + 2 * SLOT;                                           // 3 slots
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wi = wave & 3;
+  const int tiles_n = (a.N + PBN - 1) / PBN, tiles_m = (a.M + PBM - 1) / PBM;
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const uint8_t* A = reinterpret_cast<const uint8_t*>(a.A);
+  const uint8_t* W = reinterpret_cast<const uint8_t*>(a.W);
+  const int nt = a.K / KB;
+  const int my_tiles = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nt;                                       // length of this workgroup's K-step stream
+
+  const int srow = lane >> 3, cpos = lane & 7;
+  struct Src { int64_t a[4], w[4]; int m0, n0; };                        // byte offsets of this lane's 4 A pieces and 4 W pieces at K = 0
+  auto make_src = [&](int j) {
+    Src sp;
+    const int v = (int)blockIdx.x + j * (int)gridDim.x;                  // XCD x = v & 7 walks a contiguous chunk of tile ids
+    const int xcd = v & 7, seq = v >> 3;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+    tile = tile < nwg ? tile : nwg - 1;
+    sp.m0 = (tile / tiles_n) * PBM; sp.n0 = (tile % tiles_n) * PBN;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ra = 128 * g + 32 * wi + 8 * p + srow;
+      const int rw = 64 * wi + 32 * g + 8 * p + srow;
+      int gra = sp.m0 + ra; gra = gra < a.M ? gra : a.M - 1;
+      int grw = sp.n0 + rw; grw = grw < a.N ? grw : a.N - 1;
+      sp.a[p] = (int64_t)gra * a.lda + ((cpos ^ ((ra >> 1) & 7)) << 4);
+      sp.w[p] = (int64_t)grw * a.ldw + ((cpos ^ ((rw >> 1) & 7)) << 4);
+    }
+    return sp;
+  };
+  Src cur = make_src(0);
+  Src nxt = make_src(my_tiles > 1 ? 1 : 0);
+  int cur_end = nt;                                                      // stream index where `nxt` begins
+  auto load_a = [&](int u) {                                             // this wave's pieces of A_g(u)
+    if (u >= total) return;
+    const Src& sp = u >= cur_end ? nxt : cur;
+    const int kt = u >= cur_end ? u - cur_end : u - (cur_end - nt);
+    char* base = ldsA + (u & 1) * SLOT + (128 * g + 32 * wi) * KB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + sp.a[p] + kt * KB), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+  };
+  auto load_w = [&](int u) {                                             // this wave's rows of W(u)
+    if (u >= total) return;
+    const Src& sp = u >= cur_end ? nxt : cur;
+    const int kt = u >= cur_end ? u - cur_end : u - (cur_end - nt);
+    char* base = ldsW + (u % 3) * SLOT + (64 * wi + 32 * g) * KB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(W + sp.w[p] + kt * KB), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+  };
+#define SG_F8_SYNC()                                 \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_barrier();                    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+
+  // prologue: A(0), W(0), W(1) from everybody, W(2) from group 1 (group 0 issues its rows of W(2) in READ1(0))
+  load_a(0); load_w(0); load_w(1);
+  if (g == 1) { load_w(2); if (2 < total) wait_vmcnt<8>(); else if (1 < total) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+  else { if (1 < total) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+  SG_F8_SYNC();
+  if (g == 1) SG_F8_SYNC();
+
+  typedef __attribute__((ext_vector_type(8))) int i32x8;
+  union Op { bf16x8 h[2]; i32x8 v; };
+  f32x4 acc[8][4];
+  Op fa8[4], fw8[4];
+  int s = 0;
+  for (int j = 0; j < my_tiles; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nt; ++kt, ++s) {
+      const char* tA = ldsA + (s & 1) * SLOT;
+      const char* tW = ldsW + (s % 3) * SLOT;
+      // READ0(s): W fragments (kept for both phases) + A rows 0-63 of the group's half; issue A_g(s+1)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) fw8[jj].h[kk] = read_frag(tW, 64 * wi + 16 * jj + (lane & 15), kk * 4 + (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa8[i].h[kk] = read_frag(tA, 128 * g + 16 * i + (lane & 15), kk * 4 + (lane >> 4));
+      }
+      load_a(s + 1);
+      SG_F8_SYNC();
+      // MFMA0(s)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)   // cbsz = blgp = 0: both operands e4m3; scales 0x7f = 2^0 (E8M0): plain fp8 x fp8
+          acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw8[jj].v, fa8[i].v, acc[i][jj], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      __builtin_amdgcn_s_setprio(0);
+      SG_F8_SYNC();
+      // READ1(s): A rows 64-127; issue this group's rows of W(s+2) / W(s+3)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa8[i].h[kk] = read_frag(tA, 128 * g + 64 + 16 * i + (lane & 15), kk * 4 + (lane >> 4));
+      const int uw = s + 2 + g;
+      load_w(uw);
+      SG_F8_SYNC();
+      // MFMA1(s)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[4 + i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw8[jj].v, fa8[i].v, acc[4 + i][jj], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      __builtin_amdgcn_s_setprio(0);
+      if (uw < total) wait_vmcnt<4>(); else wait_vmcnt<0>();             // all but the W pieces just issued
+      SG_F8_SYNC();
+    }
+    // ---- tile end ----
+    if (g == 0) SG_F8_SYNC();                                            // align: every read of this tile's last K step has retired
+    {
+      float* patch = reinterpret_cast<float*>(ldsA + ((s - 1) & 1) * SLOT) + wave * 576;   // 8 rows x 68 floats (+pad) per wave, in the consumed A slot
+      epilogue_store8<8, 4, false, true>(acc, a, act, c_bf16, 0, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
+    }
+    cur = nxt; cur_end += nt;
+    if (j + 2 < my_tiles) nxt = make_src(j + 2);
+    SG_F8_SYNC();                                                        // the A slot used as patch is refilled from READ0 of the next step on
+    if (g == 1 && j + 1 < my_tiles) SG_F8_SYNC();                        // re-stagger
+  }
+#undef SG_F8_SYNC
+}
+
+static int launch_fp8_persist(const GemmBf16Args& a, hipStream_t s) {
+  const size_t lds = 5 * 256 * 128;                                      // 160 KiB: the whole LDS of a CU
+  auto kern = gemm_fp8_persist<false>;
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
+  const int n_cu = device_cu_count();
+  const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  SG_REQUIRE(tiles < (1ll << 31), "gemm_fp8: grid too large");
+  const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, a.act, a.c_is_bf16);
+  return SG_OK;
+}
+
 static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
   auto kern = a.f16 ? gemm_bf16_persist<true> : gemm_bf16_persist<false>;
@@ -1064,7 +1248,10 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   h.K = a.K / 2; h.lda = a.lda / 2; h.ldw = a.ldw / 2; h.strideA = a.strideA / 2; h.strideW = a.strideW / 2;
   prof_begin(PROF_GEMM_FP8, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
   // 256 x 256 x 128 B, two stages (1.47 / 1.32 / 1.64 PFLOP/s on the QKV / fc / proj shapes; the 256 x 128 three-stage tile 1.31 / 1.04 / 1.45)
-  const int rc = (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s)
+  // large shapes: the persistent ping-pong kernel (byte strides, original K); cfg 31 (tuning) forces the two-stage ring kernel instead
+  const bool persist = vec && a.batch == 1 && a.M >= 1024 && a.N >= 512 && a.K >= 512 && g_gemm_config != 31;
+  const int rc = persist ? launch_fp8_persist(a, s)
+               : (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s)
                                              : launch_ring<128, 128, 2, 2, 3, 0, 64, true>(h, vec, s);
   prof_end(PROF_GEMM_FP8, s);
   if (rc != SG_OK) return rc;
