@@ -764,7 +764,7 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 //        A(s+2), W(s+2), A(s+3) = 6), group 1 after READ(s) (tiles s+2, s+3 = 8); both before the barrier closing slot 2s+1.
 //   tile end: group 0 takes one extra barrier (both groups are then past every read of the tile's last K tile), every wave runs the
 //        coalescing epilogue through a private patch inside the just-consumed ring slot, one barrier, group 1 re-staggers.
-template <int MI, int NI, bool F16, bool SCALED = false>
+template <int MI, int NI, bool F16>
 __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
                                                 int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
@@ -799,29 +799,13 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
 #pragma unroll
     for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
   }
-  float4 cs4[NI];                                          // SCALED (fp8): per-output-channel scales of this lane's columns
-  if constexpr (SCALED) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = col0 + j * 16 + (lane >> 4) * 4;
-      cs4[j] = n + 3 < a.N ? *reinterpret_cast<const float4*>(a.col_scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-    }
-  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float4 v4[NI];
-    float al = a.alpha;
-    if constexpr (SCALED) { int m = row0 + i * 16 + (lane & 15); m = m < a.M ? m : a.M - 1; al *= a.row_scale[m]; }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      float v[4];
-      if constexpr (SCALED) {
-        v[0] = acc[i][j][0] * (al * cs4[j].x) + bias4[j].x; v[1] = acc[i][j][1] * (al * cs4[j].y) + bias4[j].y;
-        v[2] = acc[i][j][2] * (al * cs4[j].z) + bias4[j].z; v[3] = acc[i][j][3] * (al * cs4[j].w) + bias4[j].w;
-      } else {
-        v[0] = acc[i][j][0] * al + bias4[j].x; v[1] = acc[i][j][1] * al + bias4[j].y;
-        v[2] = acc[i][j][2] * al + bias4[j].z; v[3] = acc[i][j][3] * al + bias4[j].w;
-      }
+      float v[4] = {acc[i][j][0] * a.alpha + bias4[j].x, acc[i][j][1] * a.alpha + bias4[j].y, acc[i][j][2] * a.alpha + bias4[j].z,
+                    acc[i][j][3] * a.alpha + bias4[j].w};
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -1020,6 +1004,99 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 }
 
 
+
+// Epilogue of the persistent fp8 kernel.  Same patch transposition as epilogue_store8, but de-quantisation (acc * row_scale[m] *
+// col_scale[n]), bias and activation are applied AFTER it, where a lane owns the same 4 (f32) / 8 (bf16) columns for every strip:
+// one column-scale / bias quad per lane instead of one per 16-column block, and the wave's 128 row scales sit in LDS.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_store8_fp8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int row0, int col0,
+                                                    float* patch, float* srs, int lane) {
+  constexpr int TN = NI * 16, LDP = TN + 4;
+  const float* res = a.residual;
+#pragma unroll
+  for (int u = 0; u < MI * 16 / 64; ++u) {                 // the wave's MI*16 row scales -> LDS
+    int m = row0 + u * 64 + lane; m = m < a.M ? m : a.M - 1;
+    srs[u * 64 + lane] = a.row_scale[m] * a.alpha;
+  }
+  constexpr int RD = 4;
+  constexpr int LPRF = TN / 4, RPPF = 64 / LPRF, NPASS = 8 / RPPF;
+  float4 rbuf[RD][NPASS];
+  auto fetch_res = [&](int t, float4 (&dst)[NPASS]) {
+    const int rb = row0 + (t >> 1) * 16 + (t & 1) * 8;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      int m = rb + ps * RPPF + lane / LPRF; m = m < a.M ? m : a.M - 1;
+      int n = col0 + (lane % LPRF) * 4; n = n < a.N ? n : a.N - 4;
+      dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
+    }
+  };
+  const bool pipe_res = res != nullptr && !c_bf16;
+  if (pipe_res) {
+#pragma unroll
+    for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
+  }
+  auto finish = [&](float4 x, float rs, float4 cs, float4 bi) {
+    float v[4] = {x.x * (rs * cs.x) + bi.x, x.y * (rs * cs.y) + bi.y, x.z * (rs * cs.z) + bi.z, x.w * (rs * cs.w) + bi.w};
+    if (act == ACT_QUICK_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+    } else if (act == ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto quad = [&](const float* p, int n) { return (p && n + 3 < a.N) ? *reinterpret_cast<const float4*>(p + n) : make_float4(0.f, 0.f, 0.f, 0.f); };
+  // this lane's columns after the transposition
+  const int cq16 = (lane % (TN / 8)) * 8, cq32 = (lane % LPRF) * 4;
+  float4 cs0, cs1, bi0, bi1;
+  if (c_bf16) {
+    cs0 = quad(a.col_scale, col0 + cq16); cs1 = quad(a.col_scale, col0 + cq16 + 4); bi0 = quad(a.bias, col0 + cq16); bi1 = quad(a.bias, col0 + cq16 + 4);
+  } else {
+    cs0 = quad(a.col_scale, col0 + cq32); bi0 = quad(a.bias, col0 + cq32); cs1 = cs0; bi1 = bi0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {                       // two 8-row strips per 16-row MFMA tile
+      if (((lane >> 3) & 1) == hh) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          *reinterpret_cast<float4*>(patch + (lane & 7) * LDP + j * 16 + (lane >> 4) * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+      const int rloc = i * 16 + hh * 8;
+      const int rbase = row0 + rloc;
+      if (c_bf16) {                                        // 8 lanes x 16 B per row: one instruction stores the whole strip
+        const int r = lane / (TN / 8);
+        const int m = rbase + r, n = col0 + cq16;
+        const float rs = srs[rloc + r];
+        const float4 x0 = finish(*reinterpret_cast<const float4*>(patch + r * LDP + cq16), rs, cs0, bi0);
+        const float4 x1 = finish(*reinterpret_cast<const float4*>(patch + r * LDP + cq16 + 4), rs, cs1, bi1);
+        if (m < a.M && n < a.N) {
+          uint4 o; o.x = pack_bf2(x0.x, x0.y); o.y = pack_bf2(x0.z, x0.w); o.z = pack_bf2(x1.x, x1.y); o.w = pack_bf2(x1.z, x1.w);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)m * a.ldc + n) = o;
+        }
+      } else {
+        const int t = i * 2 + hh;
+#pragma unroll
+        for (int r0 = 0; r0 < 8; r0 += RPPF) {
+          const int r = r0 + lane / LPRF;
+          const int m = rbase + r, n = col0 + cq32;
+          float4 x = finish(*reinterpret_cast<const float4*>(patch + r * LDP + cq32), srs[rloc + r], cs0, bi0);
+          if (pipe_res) {
+            const float4 rr = rbuf[t % RD][r0 / RPPF];
+            x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
+          }
+          if (m < a.M && n < a.N) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)m * a.ldc + n) = x;
+        }
+        if (pipe_res && t + RD < 2 * MI) fetch_res(t + RD, rbuf[t % RD]);
+      }
+    }
+  }
+}
+
 // ---- persistent fp8 ping-pong (SG_PREC_FP8: the QKV / fc / proj linears of the ordinary blocks) ------------------------------------
 // The bf16 persistent kernel's structure carried to OCP e4m3 operands: 256 x 256 output tile, 8 waves in two groups that alternate READ /
 // MFMA segments, persistent workgroups whose K-step stream runs across output tiles, epilogue through a per-wave LDS patch.
@@ -1056,7 +1133,12 @@ __global__ __launch_bounds__(512) void gemm_fp8_persist(GemmBf16Args a, int act,
   const int total = my_tiles * nt;                                       // length of this workgroup's K-step stream
 
   const int srow = lane >> 3, cpos = lane & 7;
-  struct Src { int64_t a[4], w[4]; int m0, n0; };                        // byte offsets of this lane's 4 A pieces and 4 W pieces at K = 0
+  // Per tile a lane only keeps the first row of its 4 A pieces and of its 4 W pieces (pieces are 8 rows apart); the byte offset of a piece is
+  // rebuilt at issue time (row clamp + one 32-bit multiply: operands < 2 GiB, checked on the host), the swizzle term depends on the lane and on
+  // the parity of the piece only.  (Eight 64-bit pointers per tile for the current and the next tile do not fit next to 128 accumulators and
+  // 64 fragment registers.)
+  struct Src { int ra0, rw0, m0, n0; };
+  const int swz_e = (cpos ^ (srow >> 1)) << 4, swz_o = (cpos ^ (4 + (srow >> 1))) << 4;
   auto make_src = [&](int j) {
     Src sp;
     const int v = (int)blockIdx.x + j * (int)gridDim.x;                  // XCD x = v & 7 walks a contiguous chunk of tile ids
@@ -1064,37 +1146,39 @@ __global__ __launch_bounds__(512) void gemm_fp8_persist(GemmBf16Args a, int act,
     int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
     tile = tile < nwg ? tile : nwg - 1;
     sp.m0 = (tile / tiles_n) * PBM; sp.n0 = (tile % tiles_n) * PBN;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int ra = 128 * g + 32 * wi + 8 * p + srow;
-      const int rw = 64 * wi + 32 * g + 8 * p + srow;
-      int gra = sp.m0 + ra; gra = gra < a.M ? gra : a.M - 1;
-      int grw = sp.n0 + rw; grw = grw < a.N ? grw : a.N - 1;
-      sp.a[p] = (int64_t)gra * a.lda + ((cpos ^ ((ra >> 1) & 7)) << 4);
-      sp.w[p] = (int64_t)grw * a.ldw + ((cpos ^ ((rw >> 1) & 7)) << 4);
-    }
+    sp.ra0 = sp.m0 + 128 * g + 32 * wi + srow;
+    sp.rw0 = sp.n0 + 64 * wi + 32 * g + srow;
     return sp;
   };
   Src cur = make_src(0);
   Src nxt = make_src(my_tiles > 1 ? 1 : 0);
   int cur_end = nt;                                                      // stream index where `nxt` begins
+  const int lda = (int)a.lda, ldw = (int)a.ldw, Mm1 = a.M - 1, Nm1 = a.N - 1;
   auto load_a = [&](int u) {                                             // this wave's pieces of A_g(u)
     if (u >= total) return;
-    const Src& sp = u >= cur_end ? nxt : cur;
-    const int kt = u >= cur_end ? u - cur_end : u - (cur_end - nt);
+    const bool nx = u >= cur_end;
+    const int r0 = nx ? nxt.ra0 : cur.ra0;
+    const int kt = nx ? u - cur_end : u - (cur_end - nt);
     char* base = ldsA + (u & 1) * SLOT + (128 * g + 32 * wi) * KB;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + sp.a[p] + kt * KB), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+    for (int p = 0; p < 4; ++p) {
+      int r = r0 + 8 * p; r = r < Mm1 ? r : Mm1;
+      const int off = r * lda + ((p & 1) ? swz_o : swz_e) + kt * KB;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(A + off), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+    }
   };
   auto load_w = [&](int u) {                                             // this wave's rows of W(u)
     if (u >= total) return;
-    const Src& sp = u >= cur_end ? nxt : cur;
-    const int kt = u >= cur_end ? u - cur_end : u - (cur_end - nt);
+    const bool nx = u >= cur_end;
+    const int r0 = nx ? nxt.rw0 : cur.rw0;
+    const int kt = nx ? u - cur_end : u - (cur_end - nt);
     char* base = ldsW + (u % 3) * SLOT + (64 * wi + 32 * g) * KB;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(W + sp.w[p] + kt * KB), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+    for (int p = 0; p < 4; ++p) {
+      int r = r0 + 8 * p; r = r < Nm1 ? r : Nm1;
+      const int off = r * ldw + ((p & 1) ? swz_o : swz_e) + kt * KB;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(W + off), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+    }
   };
 #define SG_F8_SYNC()                                 \
   do {                                               \
@@ -1164,8 +1248,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_persist(GemmBf16Args a, int act,
     // ---- tile end ----
     if (g == 0) SG_F8_SYNC();                                            // align: every read of this tile's last K step has retired
     {
-      float* patch = reinterpret_cast<float*>(ldsA + ((s - 1) & 1) * SLOT) + wave * 576;   // 8 rows x 68 floats (+pad) per wave, in the consumed A slot
-      epilogue_store8<8, 4, false, true>(acc, a, act, c_bf16, 0, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
+      float* pbase = reinterpret_cast<float*>(ldsA + ((s - 1) & 1) * SLOT);    // the consumed A slot: 8 patches of 8 rows x 68 floats (+pad), then 8 x 128 row scales
+      epilogue_store8_fp8<8, 4>(acc, a, act, c_bf16, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, pbase + 8 * 576 + wave * 128, lane);
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);
@@ -1249,7 +1333,8 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   prof_begin(PROF_GEMM_FP8, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
   // 256 x 256 x 128 B, two stages (1.47 / 1.32 / 1.64 PFLOP/s on the QKV / fc / proj shapes; the 256 x 128 three-stage tile 1.31 / 1.04 / 1.45)
   // large shapes: the persistent ping-pong kernel (byte strides, original K); cfg 31 (tuning) forces the two-stage ring kernel instead
-  const bool persist = vec && a.batch == 1 && a.M >= 1024 && a.N >= 512 && a.K >= 512 && g_gemm_config != 31;
+  const bool persist = vec && a.batch == 1 && a.M >= 1024 && a.N >= 512 && a.K >= 512 && g_gemm_config != 31 &&
+                       (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);     // 32-bit byte offsets inside the kernel
   const int rc = persist ? launch_fp8_persist(a, s)
                : (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s)
                                              : launch_ring<128, 128, 2, 2, 3, 0, 64, true>(h, vec, s);

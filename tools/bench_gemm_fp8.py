@@ -1,4 +1,4 @@
-"""fp8 GEMM (v_mfma_f32_16x16x128_f8f6f4 ring kernel) on the ViT-L/14 linear shapes, random operands; bf16 persistent kernel beside it."""
+"""fp8 GEMMs (v_mfma_f32_16x16x128_f8f6f4: persistent ping-pong kernel `fp8`, two-stage ring kernel `fp8r`) on the ViT-L/14 linear shapes, random operands; bf16 persistent kernel beside it."""
 import ctypes as C
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,21 @@ for name, m, n, k, act, cbf in [("qkv", M, 3072, 1024, 0, 1), ("fc", M, 4096, 10
     bias = torch.randn(n, device=dev)
     Cc = torch.empty(m, n, device=dev, dtype=torch.bfloat16 if cbf else torch.float32)
     R = None if cbf else torch.randn(m, n, device=dev)
+    def fp8_ring():
+        lib.sg_set_gemm_config(31)                       # the non-persistent two-stage ring kernel
+        rc = lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)
+        lib.sg_set_gemm_config(-1)
+        return rc
+    # the two fp8 kernels must agree on the same operands (same products, f32 accumulation order differs only by K-step grouping)
+    assert lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream) == 0, lib.sg_last_error()
+    ref_out = Cc.float().clone()
+    assert fp8_ring() == 0, lib.sg_last_error()
+    torch.cuda.synchronize()
+    d = (Cc.float() - ref_out).abs().max().item() / ref_out.abs().max().item()
+    print(f"{name:5s} persistent vs ring fp8 kernel: max rel diff {d:.2e}", flush=True)
+    assert d < 2e-2, d
     for label, fn in (("fp8", lambda: lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)),
+                      ("fp8r", fp8_ring),
                       ("bf16", lambda: lib.sg_gemm_bf16_raw(P(A16), P(W16), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream))):
         assert fn() == 0, lib.sg_last_error()
         torch.cuda.synchronize()
