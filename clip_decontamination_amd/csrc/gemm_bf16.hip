@@ -1010,14 +1010,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 // one column-scale / bias quad per lane instead of one per 16-column block, and the wave's 128 row scales sit in LDS.
 template <int MI, int NI>
 __device__ __forceinline__ void epilogue_store8_fp8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int row0, int col0,
-                                                    float* patch, float* srs, int lane) {
+                                                    float* patch, float* srs, int lane, const float (&rs_pre)[MI * 16 / 64]) {
   constexpr int TN = NI * 16, LDP = TN + 4;
   const float* res = a.residual;
 #pragma unroll
-  for (int u = 0; u < MI * 16 / 64; ++u) {                 // the wave's MI*16 row scales -> LDS
-    int m = row0 + u * 64 + lane; m = m < a.M ? m : a.M - 1;
-    srs[u * 64 + lane] = a.row_scale[m] * a.alpha;
-  }
+  for (int u = 0; u < MI * 16 / 64; ++u) srs[u * 64 + lane] = rs_pre[u] * a.alpha;   // the wave's MI*16 row scales (fetched during the last K step) -> LDS
   constexpr int RD = 4;
   constexpr int LPRF = TN / 4, RPPF = 64 / LPRF, NPASS = 8 / RPPF;
   float4 rbuf[RD][NPASS];
@@ -1198,6 +1195,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_persist(GemmBf16Args a, int act,
   union Op { bf16x8 h[2]; i32x8 v; };
   f32x4 acc[8][4];
   Op fa8[4], fw8[4];
+  float rs_pre[2] = {1.f, 1.f};
   int s = 0;
   for (int j = 0; j < my_tiles; ++j) {
 #pragma unroll
@@ -1233,6 +1231,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_persist(GemmBf16Args a, int act,
         for (int i = 0; i < 4; ++i) fa8[i].h[kk] = read_frag(tA, 128 * g + 64 + 16 * i + (lane & 15), kk * 4 + (lane >> 4));
       const int uw = s + 2 + g;
       load_w(uw);
+      if (kt == nt - 1) {                                                  // last K step of the tile: this wave's 128 row scales for the epilogue
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) { int m = cur.m0 + 128 * g + u2 * 64 + lane; m = m < a.M ? m : a.M - 1; rs_pre[u2] = a.row_scale[m]; }
+      }
       SG_F8_SYNC();
       // MFMA1(s)
       __builtin_amdgcn_s_setprio(1);
@@ -1242,14 +1244,15 @@ __global__ __launch_bounds__(512) void gemm_fp8_persist(GemmBf16Args a, int act,
         for (int jj = 0; jj < 4; ++jj)
           acc[4 + i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw8[jj].v, fa8[i].v, acc[4 + i][jj], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       __builtin_amdgcn_s_setprio(0);
-      if (uw < total) wait_vmcnt<4>(); else wait_vmcnt<0>();             // all but the W pieces just issued
+      if (kt == nt - 1) wait_vmcnt<0>();                                 // tile end: the row scales too (they were issued after the W pieces)
+      else if (uw < total) wait_vmcnt<4>(); else wait_vmcnt<0>();        // all but the W pieces just issued
       SG_F8_SYNC();
     }
     // ---- tile end ----
     if (g == 0) SG_F8_SYNC();                                            // align: every read of this tile's last K step has retired
     {
       float* pbase = reinterpret_cast<float*>(ldsA + ((s - 1) & 1) * SLOT);    // the consumed A slot: 8 patches of 8 rows x 68 floats (+pad), then 8 x 128 row scales
-      epilogue_store8_fp8<8, 4>(acc, a, act, c_bf16, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, pbase + 8 * 576 + wave * 128, lane);
+      epilogue_store8_fp8<8, 4>(acc, a, act, c_bf16, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, pbase + 8 * 576 + wave * 128, lane, rs_pre);
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);
@@ -1333,7 +1336,9 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   prof_begin(PROF_GEMM_FP8, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
   // 256 x 256 x 128 B, two stages (1.47 / 1.32 / 1.64 PFLOP/s on the QKV / fc / proj shapes; the 256 x 128 three-stage tile 1.31 / 1.04 / 1.45)
   // large shapes: the persistent ping-pong kernel (byte strides, original K); cfg 31 (tuning) forces the two-stage ring kernel instead
-  const bool persist = vec && a.batch == 1 && a.M >= 1024 && a.N >= 512 && a.K >= 512 && g_gemm_config != 31 &&
+  // measured (tools/bench_gemm_fp8.py, R = 175 360): proj (K 4096) 1.76 vs 1.65 PFLOP/s for the persistent kernel; QKV / fc (K 1024: 8 K steps
+  // per tile, the tile switch weighs twice what it does in bf16) 1.25 / 1.23 vs 1.51 / 1.31 for the ring kernel -> persistent for long K only
+  const bool persist = vec && a.batch == 1 && a.M >= 1024 && a.N >= 512 && (a.K >= 2048 || g_gemm_config == 32) && a.K >= 512 && g_gemm_config != 31 &&
                        (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);     // 32-bit byte offsets inside the kernel
   const int rc = persist ? launch_fp8_persist(a, s)
                : (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s)

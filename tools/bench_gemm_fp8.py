@@ -26,14 +26,21 @@ for name, m, n, k, act, cbf in [("qkv", M, 3072, 1024, 0, 1), ("fc", M, 4096, 10
         lib.sg_set_gemm_config(-1)
         return rc
     # the two fp8 kernels must agree on the same operands (same products, f32 accumulation order differs only by K-step grouping)
+    lib.sg_set_gemm_config(32)
     assert lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream) == 0, lib.sg_last_error()
+    lib.sg_set_gemm_config(-1)
     ref_out = Cc.float().clone()
     assert fp8_ring() == 0, lib.sg_last_error()
     torch.cuda.synchronize()
     d = (Cc.float() - ref_out).abs().max().item() / ref_out.abs().max().item()
     print(f"{name:5s} persistent vs ring fp8 kernel: max rel diff {d:.2e}", flush=True)
     assert d < 2e-2, d
-    for label, fn in (("fp8", lambda: lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)),
+    def fp8_persist():
+        lib.sg_set_gemm_config(32)                       # force the persistent kernel on every shape
+        rc = lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)
+        lib.sg_set_gemm_config(-1)
+        return rc
+    for label, fn in (("fp8p", fp8_persist), ("fp8", lambda: lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)),
                       ("fp8r", fp8_ring),
                       ("bf16", lambda: lib.sg_gemm_bf16_raw(P(A16), P(W16), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream))):
         assert fn() == 0, lib.sg_last_error()
