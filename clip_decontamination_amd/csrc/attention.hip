@@ -174,6 +174,9 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 
     // GENERIC: the additive bias (similarity map) of the NEXT key tile is fetched one tile ahead -- 32 coalesced dword loads per
     // lane (the map is symmetric, so it is read as bias[key][query] with the queries on the lanes)
+    // Register-hungry variants (bias + several soft-maxed streams at head_dim > 64: ViT-H with SegEarth / SCLIP and a similarity map) fetch
+    // the bias of a tile when it is used instead of one tile ahead: 32 fewer live registers, no scratch (they spilled 124-590 B per lane).
+    constexpr bool BIAS_AHEAD = !(GENERIC && MULTI && DH > 64);
     float bnext[GENERIC ? 32 : 1];
     const float bias_rn = (GENERIC && a.bias_rn) ? a.bias_rn[((int64_t)b * a.H + hd) * a.N + q_ld] : 1.f;
     auto fetch_bias = [&](int kbase) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
         }
       }
     };
-    fetch_bias(0);
+    if (BIAS_AHEAD) fetch_bias(0);
     for (int k0 = 0; k0 < a.N; k0 += KT) {
       const bool has_next = k0 + KT < a.N;
       if (has_next) {                                        // next tile's loads fly while this tile computes
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
       float sc[32];
       float mloc;
       if (GENERIC) {
+        if (!BIAS_AHEAD) fetch_bias(k0);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = k0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
           if (a.resoftmax) v = (__builtin_amdgcn_exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
           sc[i] = (key < a.N && !(a.causal && key > q_glob)) ? v : -INFINITY;   // causal: text tower (build_causal_mask)
         }
-        if (has_next) fetch_bias(k0 + KT);                 // lands under this tile's softmax / PV and the next tile's QK^T
+        if (BIAS_AHEAD && has_next) fetch_bias(k0 + KT);   // lands under this tile's softmax / PV and the next tile's QK^T
         mloc = sc[0];
 #pragma unroll
         for (int i = 1; i < 32; ++i) mloc = fmaxf(mloc, sc[i]);
@@ -377,8 +381,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   const size_t lds = (size_t)2 * (TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
   const bool generic = a.bias != nullptr || a.resoftmax != 0 || a.causal != 0;
   const bool multi = !a.sum_scores && a.n_terms > 1;
-  auto kern = generic ? (multi ? attn_kernel<DH, TS, true, true, AF16> : attn_kernel<DH, TS, true, false, AF16>)
-                      : (multi ? attn_kernel<DH, TS, false, true, AF16> : attn_kernel<DH, TS, false, false, AF16>);
+  // TS == 2 means two SUMMED score terms = one stream: the multi-stream variants exist for TS == 1 only
+  constexpr bool CAN_MULTI = TS == 1;
+  SG_REQUIRE(CAN_MULTI || !multi, "attention: summed terms and separate streams are exclusive");
+  auto kern = generic ? (multi ? attn_kernel<DH, TS, true, CAN_MULTI, AF16> : attn_kernel<DH, TS, true, false, AF16>)
+                      : (multi ? attn_kernel<DH, TS, false, CAN_MULTI, AF16> : attn_kernel<DH, TS, false, false, AF16>);
   if (lds > 64 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t nqb = cdiv(a.N, QB);
   const int64_t nblk = (generic && a.bias) ? cdiv((int64_t)a.B * nqb, 8) * 8 * a.H : cdiv((int64_t)a.H * a.B, 8) * 8 * nqb;
