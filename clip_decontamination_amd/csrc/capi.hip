@@ -247,6 +247,17 @@ static int linear_fp8(const uint8_t* A8, const float* sa, int64_t lda, const uin
   g.fp8 = 1; g.row_scale = sa; g.col_scale = sw;
   return gemm_bf16(g, s);
 }
+// The MX forms (GemmBf16Args::a_mx / c_mx): A8 with E8M0 block scales a_mx [K/128][M][4] instead of row scales, and / or the output written as
+// e4m3 [M,N] + block scales c_mx_scale [N/128][M][4] (then C is unused).
+static int linear_fp8_mx(const uint8_t* A8, const float* sa, const uint8_t* a_mx, int64_t lda, const uint8_t* W8, const float* sw, const float* bias,
+                         const float* residual, void* C, int64_t ldc, bool c_f32, uint8_t* c_mx, uint8_t* c_mx_scale, int M, int N, int K, int act,
+                         hipStream_t s) {
+  GemmBf16Args g{};
+  g.A = (const bf16_t*)A8; g.lda = lda; g.W = (const bf16_t*)W8; g.ldw = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
+  g.C = c_mx ? (void*)c_mx : C; g.ldc = ldc; g.c_is_bf16 = (c_f32 && !c_mx) ? 0 : 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f;
+  g.fp8 = 1; g.row_scale = sa; g.col_scale = sw; g.a_mx = a_mx; g.c_mx = c_mx; g.c_mx_scale = c_mx_scale;
+  return gemm_bf16(g, s);
+}
 
 __global__ void zero_diag_kernel(float* sim, int n, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +296,7 @@ struct Plan {
   float *lse, *lse1, *attn_cls, *attn_diag, *out_last, *y; int32_t *idx_out, *idx_sa; void* refine_scratch;
   float *scores, *probs;
   float *omega, *qnorm, *knorm;
+  uint8_t* hmx;                                           // SG_PREC_FP8: MX block scales of h8 ([M/128][R][4] E8M0), written by the fc GEMM's epilogue
   uint8_t *x8, *h8; float *sx8, *sh8;                     // SG_PREC_FP8: quantised LN output / GELU output + per-row scales
   float *attn_avg, *sa_tmp, *sa_qk32, *sa_scores, *sa_probs;   // self-attention enhancement, mode='attention'; layer fusion
   float *lf_acc;                                              // layer fusion: the EMA of the head-averaged attention maps [B,N,N]
@@ -306,10 +318,11 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.qkv = b.take(R * 3 * d.width * e);
   p.ctx = b.take(R * d.width * e);
   p.hbuf = b.take(R * d.mlp_width * e);
-  p.x8 = p.h8 = nullptr; p.sx8 = p.sh8 = nullptr;
+  p.x8 = p.h8 = p.hmx = nullptr; p.sx8 = p.sh8 = nullptr;
   if (c->fp8) {
     p.x8 = (uint8_t*)b.take(R * d.width); p.sx8 = b.get<float>(R);
     p.h8 = (uint8_t*)b.take(R * d.mlp_width); p.sh8 = b.get<float>(R);
+    p.hmx = (uint8_t*)b.take(R * (d.mlp_width / 32 + 4));
   }
   p.xhat = nullptr; p.sim = nullptr;
   if (o->similarity_enabled) { p.xhat = b.take((size_t)B * n * d.width * e); p.sim = b.get<float>((size_t)B * n * n); }
@@ -388,6 +401,15 @@ extern "C" int sg_gemm_fp8_raw(const void* A8, const float* sa, const void* W8, 
                                void* C, int M, int N, int K, int act, int c_is_bf16, sg_stream st) {
   SG_REQUIRE(A8 && W8 && sa && sw && C, "sg_gemm_fp8_raw: null pointer");
   return linear_fp8((const uint8_t*)A8, sa, K, (const uint8_t*)W8, sw, bias, residual, C, N, !c_is_bf16, M, N, K, act, as_stream(st));
+}
+// The MXFP8 forms of the fp8 GEMM (M >= 1024, N >= 256, N % 128 == 0 when c_mx): exactly one of sa (per-row scales) / a_mx (E8M0 block scales,
+// [K/128][M][4] bytes) describes A8; when c_mx is given the result is written as e4m3 [M,N] + block scales c_mx_scale [N/128][M][4] and C is unused.
+extern "C" int sg_gemm_fp8_mx_raw(const void* A8, const float* sa, const void* a_mx, const void* W8, const float* sw, const float* bias,
+                                  const float* residual, void* C, void* c_mx, void* c_mx_scale, int M, int N, int K, int act, int c_is_bf16, sg_stream st) {
+  SG_REQUIRE(A8 && W8 && sw && ((sa != nullptr) != (a_mx != nullptr)) && (C || c_mx), "sg_gemm_fp8_mx_raw: bad pointers");
+  SG_REQUIRE(!c_mx || c_mx_scale, "sg_gemm_fp8_mx_raw: c_mx needs c_mx_scale");
+  return linear_fp8_mx((const uint8_t*)A8, sa, (const uint8_t*)a_mx, K, (const uint8_t*)W8, sw, bias, residual, C, N, !c_is_bf16, (uint8_t*)c_mx,
+                       (uint8_t*)c_mx_scale, M, N, K, act, as_stream(st));
 }
 // rows of f32 -> e4m3 + per-row absmax scale (scale[r] = max|x[r,:]| / 448), the quantiser both fp8 operands go through
 extern "C" int sg_quantize_rows_fp8(const float* x, int64_t rows, int D, void* y, float* scale, sg_stream st) {
@@ -563,6 +585,12 @@ static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
   const int act = d.quick_gelu ? ACT_QUICK_GELU : ACT_GELU;
   if (c->fp8 && p.x8 && L.w_fc8) {                          // fp8 linears: LN -> e4m3 + row scale; GELU output re-quantised per row
     SG_TRY(layernorm_fp8(x, D, L.ln2_g, L.ln2_b, p.x8, D, p.sx8, R, D, 1e-5f, s));
+    if (R >= 1024 && M % 128 == 0 && D % 256 == 0 && get_gemm_config() != 33) {
+      // MXFP8 hand-off: the fc epilogue writes GELU(h) as e4m3 with one power-of-two scale per 32 columns, which the proj GEMM's scaled MFMA
+      // consumes directly -- no [R, M] 2-byte intermediate and no separate row-quantisation pass (finer-grained scales than one per row, too)
+      SG_TRY(linear_fp8_mx(p.x8, p.sx8, nullptr, D, L.w_fc8, L.s_fc, L.b_fc, nullptr, nullptr, M, false, p.h8, p.hmx, (int)R, M, D, act, s));
+      return linear_fp8_mx(p.h8, nullptr, p.hmx, M, L.w_proj8, L.s_proj, L.b_proj, x, x, D, true, nullptr, nullptr, (int)R, D, M, ACT_NONE, s);
+    }
     SG_TRY(linear_fp8(p.x8, p.sx8, D, L.w_fc8, L.s_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
     SG_TRY(quantize_rows_fp8(p.hbuf, 1, M, p.h8, M, p.sh8, R, M, s));
     return linear_fp8(p.h8, p.sh8, M, L.w_proj8, L.s_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s);

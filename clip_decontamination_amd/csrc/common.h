@@ -154,6 +154,12 @@ struct GemmBf16Args {
   // fp8 mode (fp8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K % 128 == 0); lda / ldw / K stay in ELEMENTS (= bytes);
   // the accumulator is de-quantised with row_scale[m] * col_scale[n] (per-token / per-output-channel absmax scales).
   int fp8; const float* row_scale; const float* col_scale;
+  // fp8 mode, MX block scaling (OCP MXFP8: one E8M0 power-of-two scale per 32 consecutive K elements, consumed by the scale operands of
+  // v_mfma_scale_f32_16x16x128_f8f6f4 -- the scale of K block b of row r is read from lane r + 16 b, tools/mx_probe.hip):
+  //   a_mx      : A's block scales, laid out [K/128][M][4] bytes (the four blocks of one K step of a row are one dword); row_scale is then unused
+  //   c_mx      : write C as e4m3 bytes [M, N] with block scales c_mx_scale in the same [N/128][M][4] layout (C / c_is_bf16 ignored):
+  //               the next linear's MX operand straight out of this epilogue, no separate quantisation pass
+  const uint8_t* a_mx; uint8_t* c_mx; uint8_t* c_mx_scale;
   // persistent kernel only: row-dot epilogue.  With v = alpha * acc + bias and r = residual, NOTHING is stored to C; instead
   // rowdot[m * rowdot_ld + n / 64] = sum over the 64 columns [n, n + 64) of v * (2 r + v)  (= |r + v|^2 - |r|^2 of that column slice):
   // the JBU tail needs only the norm of x + 0.1 * conv1x1(x), never the C x S^2 map itself.  f32 residual required.
@@ -165,6 +171,7 @@ struct GemmBf16Args {
   int ngroup;                                // row-dot mode: `residual` points to bf16 (same ldr, in elements) instead of f32
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
+int get_gemm_config();
 void set_gemm_config(int c);   // tuning hook (per calling thread): -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
 
 // f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];

@@ -188,7 +188,28 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
       for (int r0 = 0; r0 < 16; r0 += RPP) {
         const int r = r0 + lane / LPR, cq = (lane % LPR) * 8;
         const int m = rbase + r, n = col0 + cq;
-        if (r < 16 && m < a.M && n < a.N) {
+        if (a.c_mx) {                                       // MXFP8 output: e4m3 + one E8M0 scale per 32 columns (4 adjacent lanes of a row)
+          static_assert(TN % 32 == 0, "MX blocks are 32 columns");
+          const bool ok = r < 16 && m < a.M && n < a.N;
+          const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
+          float am = fmaxf(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fmaxf(fabsf(x0.z), fabsf(x0.w))),
+                           fmaxf(fmaxf(fabsf(x1.x), fabsf(x1.y)), fmaxf(fabsf(x1.z), fabsf(x1.w))));
+          am = fmaxf(am, __shfl_xor(am, 1, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64));
+          // smallest power of two 2^(E-127) with amax / 2^(E-127) <= 448 = 1.75 * 2^8: exponent of amax - 8, + 1 if its mantissa exceeds 1.75's
+          const uint32_t ab = __float_as_uint(am);
+          int E = (int)(ab >> 23) - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0);
+          E = E < 0 ? 0 : E;
+          const float inv = __uint_as_float((uint32_t)(254 - E) << 23);           // 2^(127 - E)
+          if (ok) {
+            int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x0.x * inv, x0.y * inv, 0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x0.z * inv, x0.w * inv, w0, true);
+            int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x1.x * inv, x1.y * inv, 0, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x1.z * inv, x1.w * inv, w1, true);
+            *reinterpret_cast<uint2*>(a.c_mx + (int64_t)m * a.ldc + n) = make_uint2((uint32_t)w0, (uint32_t)w1);
+            if ((lane & 3) == 0) { const int nb = n >> 5; a.c_mx_scale[((int64_t)(nb >> 2) * a.M + m) * 4 + (nb & 3)] = (uint8_t)E; }
+          }
+        } else if (r < 16 && m < a.M && n < a.N) {
           const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
           const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
           uint4 o; o.x = pack_half2<F16>(x0.x, x0.y); o.y = pack_half2<F16>(x0.z, x0.w); o.z = pack_half2<F16>(x1.x, x1.y); o.w = pack_half2<F16>(x1.z, x1.w);
@@ -233,13 +254,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 64 'bf16' = 128 fp8 per row), so staging, swizzle and fragment reads are unchanged; the two 16-byte fragment reads of a K tile
 // are concatenated into the 32-byte operand of ONE v_mfma_f32_16x16x128_f8f6f4 (both operands use the same K permutation).
 // The legacy v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate on gfx950 (tools/mfma_rate.hip: 2.1 vs 4.8 PFLOP/s), so it is not used.
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
+// MXA (fp8 only): A carries MX block scales (GemmBf16Args::a_mx): every K tile stages one more piece -- the dwords holding the four E8M0
+// scales of each A row -- behind the operand image, and the MFMA's second scale operand gets the lane's own byte.
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MI = TM / 16, NI = TN / 16;
   constexpr int RPS = BKT == 64 ? 8 : 16;                // rows per 1 KiB slab (row = BKT * 2 bytes)
   constexpr int SLABS = (BM_ + BN_) / RPS;               // 1 KiB slabs per K tile
-  constexpr int G = SLABS / NW;                          // global_load_lds per thread per K tile
-  constexpr int STAGE_BYTES = (BM_ + BN_) * BKT * 2;
+  constexpr int G = SLABS / NW + (MXA ? 1 : 0);          // global_load_lds per thread per K tile
+  constexpr int OPER_BYTES = (BM_ + BN_) * BKT * 2;
+  constexpr int STAGE_BYTES = OPER_BYTES + (MXA ? BM_ * 4 : 0);
+  static_assert(!MXA || (FP8 && BM_ == 256 && NW >= 4), "MX block scales: fp8 256-row tiles");
   static_assert(SLABS % NW == 0, "slabs must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,8 +283,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
 
   auto stage = [&](int t, int slot) {
     char* base = lds + slot * STAGE_BYTES;
+    if constexpr (MXA) {                                   // 64 rows x 4 scale bytes per wave-instruction; waves >= 4 repeat the rows of waves 0-3 (same bytes, same place)
+      int gr = m0 + (wave & 3) * 64 + lane; gr = gr < a.M ? gr : a.M - 1;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a.a_mx + ((int64_t)t * a.M + gr) * 4), (lds_ptr_t)(base + OPER_BYTES + (wave & 3) * 256), 4, 0, 0);
+    }
 #pragma unroll
-    for (int p = 0; p < G; ++p) {
+    for (int p = 0; p < G - (MXA ? 1 : 0); ++p) {
       const int slab = p * NW + wave;                      // wave-uniform
       const int r = slab * RPS + (BKT == 64 ? (lane >> 3) : (lane >> 2));   // row inside the stacked [A rows | W rows] image
       const int c = BKT == 64 ? (lane & 7) : (lane & 3);
@@ -301,11 +330,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
       Op fa8[MI], fw8[NI];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const int chunk = kk * 4 + (lane >> 4);
+        const int chunk = kk * 4 + (lane >> 4);            // the instruction's own K order: dwords 0-3 of lane block g are K 16g..16g+15, dwords 4-7 are K 64+16g.. (tools/mx_probe.hip)
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa8[i].h[kk] = read_frag(bufA, wave_m * TM + i * 16 + (lane & 15), chunk);
 #pragma unroll
         for (int j = 0; j < NI; ++j) fw8[j].h[kk] = read_frag(bufW, wave_n * TN + j * 16 + (lane & 15), chunk);
+      }
+      if constexpr (MXA) {
+        // the scale of K block b (K 32b..32b+31) of row r is taken from lane r + 16 b (NOT "the lane's own 32 bytes": those straddle
+        // blocks g/2 and 2 + g/2 -- tools/mx_probe.hip run 4): lane (r, g) supplies byte g of the row's scale dword, in byte 0 (opsel 0)
+        const uint32_t* sS = reinterpret_cast<const uint32_t*>(bufA + OPER_BYTES);
+        int sa[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) sa[i] = (int)(sS[wave_m * TM + i * 16 + (lane & 15)] >> (8 * (lane >> 4)));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)   // operands are swapped (W rows on the first port): A's block scale is the SECOND scale operand
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw8[j].v, fa8[i].v, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, sa[i]);
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -1299,16 +1342,17 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
 }
 
 static thread_local int g_gemm_config = -1;                // -1 = pick per shape (tuning override, per calling thread)
+int get_gemm_config() { return g_gemm_config; }
 void set_gemm_config(int c) {
   if (c >= 1000) { g_gemm_order = c - 1001; return; }      // 1000 -> -1 (automatic), 1001 -> 0 (raster), 1001 + v -> N-group size v
   g_gemm_config = c;
 }
 
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false>
 static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
-  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8, F16>;
-  const size_t lds = (size_t)STAGES * (BM_ + BN_) * BKT * 2;
+  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8, F16, MXA>;
+  const size_t lds = (size_t)STAGES * ((BM_ + BN_) * BKT * 2 + (MXA ? BM_ * 4 : 0));
   if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
@@ -1326,7 +1370,8 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   SG_REQUIRE(a.K % 128 == 0, "gemm_fp8: K=%d must be a multiple of 128", a.K);
   SG_REQUIRE(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.strideA % 16 == 0 && a.strideW % 16 == 0, "gemm_fp8: operand strides must be multiples of 16 bytes");
   SG_REQUIRE((((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0, "gemm_fp8: operands must be 16-byte aligned");
-  SG_REQUIRE(a.row_scale && a.col_scale, "gemm_fp8: row_scale / col_scale are required");
+  SG_REQUIRE(a.col_scale && (a.row_scale || a.a_mx), "gemm_fp8: col_scale and (row_scale or MX block scales) are required");
+  if (a.c_mx) SG_REQUIRE(a.c_mx_scale && a.N % 128 == 0 && a.ldc % 8 == 0 && !a.residual, "gemm_fp8: MX output needs c_mx_scale, N %% 128 == 0, no residual");
   SG_REQUIRE(a.act >= 0 && a.act <= 2, "gemm_fp8: bad act %d", a.act);
   bool vec = (a.N % 8 == 0) && (a.ldc % 8 == 0) && (a.strideC % 8 == 0) && ((((uintptr_t)a.C) & 15) == 0) && ((((uintptr_t)a.col_scale) & 15) == 0);
   if (a.bias) vec = vec && ((((uintptr_t)a.bias) & 15) == 0);
@@ -1338,6 +1383,15 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   // large shapes: the persistent ping-pong kernel (byte strides, original K); cfg 31 (tuning) forces the two-stage ring kernel instead
   // measured (tools/bench_gemm_fp8.py, R = 175 360): proj (K 4096) 1.76 vs 1.65 PFLOP/s for the persistent kernel; QKV / fc (K 1024: 8 K steps
   // per tile, the tile switch weighs twice what it does in bf16) 1.25 / 1.23 vs 1.51 / 1.31 for the ring kernel -> persistent for long K only
+  const bool mx = a.a_mx != nullptr || a.c_mx != nullptr;
+  if (mx) {                                               // MX operands / MX output live in the ring kernel (the persistent kernel's LDS is full)
+    SG_REQUIRE(vec && a.batch == 1 && a.M >= 1024 && a.N >= 256, "gemm_fp8: the MX forms need the large-shape vector path");
+    const int rcm = a.a_mx ? launch_ring<256, 256, 2, 4, 2, 0, 64, true, false, true>(h, vec, s) : launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s);
+    prof_end(PROF_GEMM_FP8, s);
+    if (rcm != SG_OK) return rcm;
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+  }
   const bool persist = vec && a.batch == 1 && a.M >= 1024 && a.N >= 512 && (a.K >= 2048 || g_gemm_config == 32) && a.K >= 512 && g_gemm_config != 31 &&
                        (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);     // 32-bit byte offsets inside the kernel
   const int rc = persist ? launch_fp8_persist(a, s)

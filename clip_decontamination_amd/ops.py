@@ -104,6 +104,28 @@ def quantize_rows_fp8(x):
 
 
 @on_tensor_device
+def gemm_fp8_mx(a8, w8, sw, sa=None, a_mx=None, bias=None, residual=None, act: int = 0, out_bf16: bool = False, mx_out: bool = False):
+    """The MXFP8 forms of the fp8 GEMM (include/segearth_hip.h: sg_gemm_fp8_mx_raw) on caller-quantised operands.  a8 [M,K] u8 with
+    either per-row scales `sa` [M] or E8M0 block scales `a_mx` [K/128, M, 4] u8; w8 [N,K] u8 with per-row scales sw [N].
+    Returns C, or (c8 [M,N] u8, c_scale [N/128, M, 4] u8) with mx_out."""
+    lib = _lib.load()
+    M, K = a8.shape
+    N = w8.shape[0]
+    bias = None if bias is None else _f32(bias)
+    residual = None if residual is None else _f32(residual)
+    if mx_out:
+        c8 = torch.empty(M, N, dtype=torch.uint8, device=a8.device)
+        cs = torch.zeros(N // 128, M, 4, dtype=torch.uint8, device=a8.device)
+        out = None
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a8.device)
+        c8 = cs = None
+    check(lib.sg_gemm_fp8_mx_raw(ptr(a8), ptr(sa), ptr(a_mx), ptr(w8), ptr(sw), ptr(bias), ptr(residual), ptr(out), ptr(c8), ptr(cs),
+                                 M, N, K, act, int(out_bf16), stream_ptr()), "sg_gemm_fp8_mx_raw")
+    return (c8, cs) if mx_out else out
+
+
+@on_tensor_device
 def linear_fp8(A, W, bias=None, residual=None, act: int = 0, out_bf16: bool = False):
     """act(dequant(fp8(A) @ fp8(W)^T) + bias) (+ residual) on the fp8 MFMA path; A [M,K], W [N,K] f32, K % 128 == 0."""
     lib = _lib.load()

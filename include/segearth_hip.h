@@ -219,6 +219,14 @@ int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias, const floa
  * A8 [M,K], W8 [N,K] bytes, K % 128 == 0; sg_quantize_rows_fp8 produces an operand and its per-row scales (absmax / 448). */
 int sg_gemm_fp8_raw(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, const float* residual, void* C,
                     int M, int N, int K, int act, int c_is_bf16, sg_stream s);
+/* The MXFP8 forms of the same GEMM (OCP microscaling: one E8M0 power-of-two scale, value 2^(byte - 127), per 32 consecutive K elements,
+ * fed to the scale operands of v_mfma_scale_f32_16x16x128_f8f6f4).  Block scales of an [M, K] operand are laid out [K/128][M][4] bytes
+ * (the four blocks of one 128-wide K step of a row form one dword).  Exactly one of `sa` (per-row f32 scales) / `a_mx` (block scales)
+ * describes A8.  With `c_mx` the result act(..) is written as e4m3 bytes [M,N] with block scales `c_mx_scale` [N/128][M][4] -- the next
+ * linear's MX operand straight out of the epilogue (the tower's fc -> proj hand-off in SG_PREC_FP8) -- and C / residual are unused.
+ * Needs M >= 1024, N >= 256, N % 8 == 0 (N % 128 == 0 with c_mx), K % 128 == 0. */
+int sg_gemm_fp8_mx_raw(const void* A8, const float* sa, const void* a_mx, const void* W8, const float* sw, const float* bias,
+                       const float* residual, void* C, void* c_mx, void* c_mx_scale, int M, int N, int K, int act, int c_is_bf16, sg_stream s);
 int sg_quantize_rows_fp8(const float* x, int64_t rows, int D, void* y, float* scale, sg_stream s);
 int sg_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, sg_stream s);
 /* multi-term attention over packed qkv [B,N,3D] (rows q|k|v, nn.MultiheadAttention order);

@@ -63,6 +63,81 @@ def test_fp8_gemm_exact_on_its_own_operands(M, N, K, act, res, obf):
     assert (out.float() - exact).abs().max().item() < 0.08 * exact.abs().max().item()
 
 
+def _mx_decode(c8, cs):
+    """e4m3 bytes [M,N] + E8M0 block scales [N/128, M, 4] -> f32 [M,N]."""
+    M, N = c8.shape
+    e = cs.permute(1, 0, 2).reshape(M, N // 32).to(torch.int32)                    # [M, N/32]
+    sc = torch.pow(2.0, (e - 127).double()).float()
+    return c8.view(torch.float8_e4m3fn).float() * sc.repeat_interleave(32, dim=1), e
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1370, 1024, 1024, 0), (2055, 4096, 1024, 1), (1024, 256, 128, 2)])
+def test_fp8_gemm_mx_output(M, N, K, act):
+    """The block-scaled epilogue: every 32-column block of act(A.W^T + bias) is stored as e4m3 times the smallest power of two that
+    keeps the block inside +-448 -- tight scale, values within half an e4m3 step of the f32 result."""
+    from clip_decontamination_amd import ops
+    A, W = rnd(M, K, seed=2).to(DEV), (rnd(N, K, seed=3) * K ** -0.5).to(DEV)
+    A = A * torch.logspace(-2, 2, M, device=DEV).view(M, 1)                         # rows of very different magnitude
+    bias = rnd(N, seed=4).to(DEV)
+    a8, sa = ops.quantize_rows_fp8(A)
+    w8, sw = ops.quantize_rows_fp8(W)
+    ref = ops.gemm_fp8_mx(a8, w8, sw, sa=sa, bias=bias, act=act)                    # same kernel, f32 output
+    c8, cs = ops.gemm_fp8_mx(a8, w8, sw, sa=sa, bias=bias, act=act, mx_out=True)
+    got, e = _mx_decode(c8, cs)
+    blk = ref.view(M, N // 32, 32).abs().amax(dim=2)                                # block absmax of the f32 result
+    qmax = (got.view(M, N // 32, 32).abs().amax(dim=2) / torch.pow(2.0, (e - 127).float().to(DEV)))
+    live = blk > 1e-30
+    assert (qmax[live] <= 448).all() and (qmax[live] > 208).all()                   # the scale is the tightest power of two (448/2 less one step)
+    step = torch.maximum(ref.abs() * 2.0 ** -4, (blk * 2.0 ** -9).repeat_interleave(32, dim=1))   # half a step; subnormal floor relative to the block scale
+    assert ((got - ref).abs() <= step * 1.001).all()
+
+
+@pytest.mark.parametrize("M,N,K,res,obf", [(1370, 1024, 4096, True, False), (1024, 256, 128, False, False), (3000, 1280, 5120, True, True)])
+def test_fp8_gemm_mx_operand_exact(M, N, K, res, obf):
+    """A with per-(row, 32-element) E8M0 scales through the scale operand of the MFMA: equals the f64 product of the decoded operands."""
+    from clip_decontamination_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a_f = rnd(M, K, seed=6)
+    a8 = a_f.to(torch.float8_e4m3fn).view(torch.uint8).to(DEV)                      # values in [-4, 4]: plain e4m3 bytes
+    a_mx = torch.randint(118, 136, (K // 128, M, 4), generator=g, dtype=torch.uint8).to(DEV)
+    W = (rnd(N, K, seed=7) * K ** -0.5).to(DEV)
+    w8, sw = ops.quantize_rows_fp8(W)
+    bias = rnd(N, seed=8).to(DEV)
+    R = rnd(M, N, seed=9).to(DEV) if res else None
+    out = ops.gemm_fp8_mx(a8, w8, sw, a_mx=a_mx, bias=bias, residual=R, out_bf16=obf)
+    a, _ = _mx_decode(a8, a_mx)
+    w = w8.view(torch.float8_e4m3fn).float() * sw.view(-1, 1)
+    ref = (a.double() @ w.double().T).float() + bias
+    if R is not None:
+        ref = ref + R
+    tol = (2e-2 if obf else 2e-4) * ref.abs().max().item()
+    assert (out.float() - ref).abs().max().item() < tol
+
+
+def test_fp8_mx_chain_matches_row_scaled_chain():
+    """fc -> MX hand-off -> proj (what the tower's MLP does in SG_PREC_FP8) against the f32 MLP: the block scales are finer than the
+    per-row ones, so the error must not exceed the row-scaled chain's."""
+    from clip_decontamination_amd import ops
+    M, D, H = 2055, 1024, 4096
+    x = rnd(M, D, seed=11).to(DEV)
+    W1, b1 = (rnd(H, D, seed=12) * D ** -0.5).to(DEV), rnd(H, seed=13).to(DEV) * 0.1
+    W2, b2 = (rnd(D, H, seed=14) * H ** -0.5).to(DEV), rnd(D, seed=15).to(DEV) * 0.1
+    x8, sx = ops.quantize_rows_fp8(x)
+    w18, s1 = ops.quantize_rows_fp8(W1)
+    w28, s2 = ops.quantize_rows_fp8(W2)
+    h8, hs = ops.gemm_fp8_mx(x8, w18, s1, sa=sx, bias=b1, act=1, mx_out=True)
+    y_mx = ops.gemm_fp8_mx(h8, w28, s2, a_mx=hs, bias=b2)
+    h = ops.gemm_fp8_mx(x8, w18, s1, sa=sx, bias=b1, act=1)
+    hq, sh = ops.quantize_rows_fp8(h)
+    y_row = ops.gemm_fp8_mx(hq, w28, s2, sa=sh, bias=b2)
+    hx = x @ W1.T + b1
+    exact = (hx * torch.sigmoid(1.702 * hx)) @ W2.T + b2
+    e_mx = (y_mx - exact).abs().mean().item()
+    e_row = (y_row - exact).abs().mean().item()
+    print(f"MLP chain mean |err|: MX hand-off {e_mx:.3e}, row-scaled {e_row:.3e}")
+    assert e_mx <= e_row * 1.05
+
+
 def _tower(name, prec):
     from clip_decontamination_amd.engine import HipVisionTower, HipCLIP
     cfg = Wt.vit_config(name)

@@ -40,7 +40,16 @@ for name, m, n, k, act, cbf in [("qkv", M, 3072, 1024, 0, 1), ("fc", M, 4096, 10
         rc = lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)
         lib.sg_set_gemm_config(-1)
         return rc
-    for label, fn in (("fp8p", fp8_persist), ("fp8", lambda: lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)),
+    # the MX forms: fc writing e4m3 + block scales, proj reading them
+    c8 = torch.empty(m, n, device=dev, dtype=torch.uint8) if name == "fc" else None
+    cs = torch.zeros(n // 128, m, 4, device=dev, dtype=torch.uint8) if name == "fc" else None
+    amx = torch.full((k // 128, m, 4), 127, device=dev, dtype=torch.uint8) if name == "proj" else None
+    mx = []
+    if name == "fc":
+        mx = [("mxout", lambda: lib.sg_gemm_fp8_mx_raw(P(a8), P(sa), None, P(w8), P(sw), P(bias), None, None, P(c8), P(cs), m, n, k, act, 1, stream))]
+    if name == "proj":
+        mx = [("mxin", lambda: lib.sg_gemm_fp8_mx_raw(P(a8), None, P(amx), P(w8), P(sw), P(bias), P(R), P(Cc), None, None, m, n, k, act, cbf, stream))]
+    for label, fn in (*mx, ("fp8p", fp8_persist), ("fp8", lambda: lib.sg_gemm_fp8_raw(P(a8), P(sa), P(w8), P(sw), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream)),
                       ("fp8r", fp8_ring),
                       ("bf16", lambda: lib.sg_gemm_bf16_raw(P(A16), P(W16), P(bias), P(R), P(Cc), m, n, k, act, cbf, stream))):
         assert fn() == 0, lib.sg_last_error()
