@@ -45,18 +45,32 @@ template <int DH> struct AttnCfg {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-// HBM -> registers (issued early, T14 async-stage split) and registers -> LDS (after the compute phase)
+// HBM -> registers (issued early, T14 async-stage split) and registers -> LDS (after the compute phase).
+// No multiplies and no branches per tile: a chunk's element offset is min(tile base + its offset inside the tile, offset of the same
+// column in the last row) -- rows past the end read row N-1 (masked in the scores).  RowMap holds the per-thread constants.
+template <int DH> struct RowMap { int off[AttnCfg<DH>::NL], omax[AttnCfg<DH>::NL]; };
 template <int DH>
-__device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, int64_t st, int row0, int N, int tid,
-                                          u32x4 (&reg)[AttnCfg<DH>::NL]) {
+__device__ __forceinline__ RowMap<DH> make_row_map(int64_t st, int N, int tid) {
   constexpr int CH = AttnCfg<DH>::CH;
+  RowMap<DH> m;
 #pragma unroll
   for (int i = 0; i < AttnCfg<DH>::NL; ++i) {
     int idx = tid + i * 256;
     idx = idx < KT * CH ? idx : KT * CH - 1;           // ragged chunk counts (dh 80): load a valid duplicate, never stored
     const int r = idx / CH, c = idx % CH;
-    int gr = row0 + r; gr = gr < N ? gr : N - 1;       // rows past the end are masked in the scores
-    reg[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)gr * st + c * 8);
+    m.off[i] = r * (int)st + c * 8;
+    m.omax[i] = (N - 1) * (int)st + c * 8;
+  }
+  return m;
+}
+template <int DH>
+__device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, int64_t st, int row0, const RowMap<DH>& m,
+                                          u32x4 (&reg)[AttnCfg<DH>::NL]) {
+  const int base = row0 * (int)st;
+#pragma unroll
+  for (int i = 0; i < AttnCfg<DH>::NL; ++i) {
+    const int o = base + m.off[i];
+    reg[i] = *reinterpret_cast<const u32x4*>(src + (o < m.omax[i] ? o : m.omax[i]));
   }
 }
 template <int DH>
@@ -111,6 +125,8 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
   const float lse1_2 = (GENERIC && a.resoftmax) ? a.lse_in[((int64_t)b * a.H + hd) * a.N + q_ld] * LOG2E : 0.f;
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;               // transposed-read lane roles
 
+  const RowMap<DH> kmap = make_row_map<DH>(a.st, a.N, tid), vmap = make_row_map<DH>(a.v_st, a.N, tid);
+
   f32x16 o_tot[MULTI ? C::DVT : 1];
   if (MULTI) {
 #pragma unroll
@@ -164,8 +180,8 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 
     u32x4 kreg[TS][C::NL], vreg[C::NL];
 #pragma unroll
-    for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, 0, a.N, tid, kreg[t]);
-    if (do_pv) load_rows<DH>(vbase, a.v_st, 0, a.N, tid, vreg);
+    for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, 0, kmap, kreg[t]);
+    if (do_pv) load_rows<DH>(vbase, a.v_st, 0, vmap, vreg);
 #pragma unroll
     for (int t = 0; t < TS; ++t) store_rows<DH>(sbuf + t * KT * C::K_LD, C::K_LD, tid, kreg[t]);
     if (do_pv) store_rows<DH>(sbuf + TS * KT * C::K_LD, C::V_LD, tid, vreg);
@@ -195,8 +211,8 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
       const bool has_next = k0 + KT < a.N;
       if (has_next) {                                        // next tile's loads fly while this tile computes
 #pragma unroll
-        for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, k0 + KT, a.N, tid, kreg[t]);
-        if (do_pv) load_rows<DH>(vbase, a.v_st, k0 + KT, a.N, tid, vreg);
+        for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, k0 + KT, kmap, kreg[t]);
+        if (do_pv) load_rows<DH>(vbase, a.v_st, k0 + KT, vmap, vreg);
       }
       const bf16_t* sK = sbuf + cur * BUF;
       const bf16_t* sV = sK + TS * KT * C::K_LD;
@@ -413,6 +429,7 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
   SG_REQUIRE(a.sb % 8 == 0 && a.st % 8 == 0 && a.v_sb % 8 == 0 && a.v_st % 8 == 0, "attention: strides must be multiples of 8 elements");
   SG_REQUIRE(!a.resoftmax || a.lse_in, "attention: resoftmax needs lse_in");
   SG_REQUIRE(a.ctx || a.lse_out, "attention: nothing to compute");
+  SG_REQUIRE((int64_t)(a.N + 2 * KT) * a.st < (1ll << 31) && (int64_t)(a.N + 2 * KT) * a.v_st < (1ll << 31), "attention: token stride too large for 32-bit row offsets");
   const int ts = a.sum_scores ? a.n_terms : 1;
   SG_REQUIRE(ts <= 2, "attention: at most 2 summed terms");
 #define SG_ATTN_CASE(DHV)                                                   \
