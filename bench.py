@@ -105,12 +105,16 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="experiment: split a rank's tiles over this many HIP streams (tails of one half overlap the other)")
     ap.add_argument("--upsampler", default="none", choices=["none", "jbu_one", "jbu_stack"],
                     help="per-pixel logits through the SimFeatUp JBU upsampler (BASELINE configs[3]); multi-rank: halo tiles travel point to point")
+    ap.add_argument("--tuning", type=int, default=None, help="experiment: a library tuning code for sg_set_gemm_config (34 = LayerNorm as its own pass, ...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-check", action="store_true",
                     help="profiling runs only: skip the single-tile re-computations after the timed region, so that rocprofv3's per-kernel averages cover the timed launch shape alone")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
+    if args.tuning is not None:
+        from clip_decontamination_amd import _lib as _sg_lib
+        _sg_lib.load().sg_set_gemm_config(int(args.tuning))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

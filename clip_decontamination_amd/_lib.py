@@ -70,6 +70,8 @@ SIGNATURES = {
     "sg_op_linear": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),
     "sg_gemm_bf16_raw": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "sg_gemm_fp8_raw": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "sg_op_ln_chain_scratch_bytes": (Z, [I, I, I, I]),
+    "sg_op_ln_chain": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "sg_gemm_fp8_mx_raw": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sg_quantize_rows_fp8": (I, [P, L, I, P, P, P]),
     "sg_op_layernorm": (I, [P, P, P, P, I, I, F, P]),

@@ -86,6 +86,11 @@ struct LayerW {
   uint8_t *w_qkv8, *w_fc8, *w_proj8;                   // SG_PREC_FP8: e4m3 copies + per-output-channel scales
   float *s_qkv, *s_fc, *s_proj;
   float *b_qkv, *b_out, *b_fc, *b_proj, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  // LayerNorm folded into the GEMMs (2-byte modes without fp8 linears): W' = gamma o W, c = row sums of W', b' = b + W.beta  (rowops.h)
+  void *w_qkv_f = nullptr, *w_fc_f = nullptr;
+  float *c_qkv = nullptr, *c_fc = nullptr, *bf_qkv = nullptr, *bf_fc = nullptr;
+  float *stage_qkv = nullptr, *stage_fc = nullptr;     // f32 copies of the two weights, kept from sg_vit_set_tensor to sg_vit_finalize only
+  bool folded = false;
 };
 
 }  // namespace sg
@@ -237,6 +242,25 @@ static int linear(int bf16, const void* A, int64_t lda, const void* W, const flo
   g.C = (float*)C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.batch = 1; g.inner = 1; g.act = act; g.alpha = 1.f;
   return gemm_f32(g, s);
 }
+// The two GEMM forms a folded LayerNorm is made of (2-byte modes, persistent kernel; GemmBf16Args::copy16 / ln_stats):
+//   producer: C (f32) = A.W^T + bias (+ residual), plus its 2-byte copy `copy16` [M, N] and the slice statistics of the finished rows
+//   consumer: C (2-byte) = act(rstd (A.W'^T - mean c) + b') with (mean, rstd) per row
+static int linear_ln_producer(int hk, const void* A, int64_t lda, const void* W, const float* bias, const float* residual, float* C, int64_t ldc,
+                              void* copy16, float* slice_stats, int M, int N, int K, hipStream_t s) {
+  GemmBf16Args g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
+  g.C = C; g.ldc = ldc; g.c_is_bf16 = 0; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = ACT_NONE; g.alpha = 1.f; g.f16 = hk == HK_F16;
+  g.copy16 = copy16; g.ld16 = N; g.row_stats = slice_stats;
+  return gemm_bf16(g, s);
+}
+static int linear_ln_consumer(int hk, const void* A, int64_t lda, const void* Wf, const float* bias_f, const float* c_vec, const float* mean_rstd,
+                              void* C, int64_t ldc, int M, int N, int K, int act, hipStream_t s) {
+  GemmBf16Args g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)Wf; g.ldw = K; g.bias = bias_f;
+  g.C = C; g.ldc = ldc; g.c_is_bf16 = 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f; g.f16 = hk == HK_F16;
+  g.ln_stats = mean_rstd; g.ln_c = c_vec;
+  return gemm_bf16(g, s);
+}
 
 // C = act((A8 . W8^T) * sa[m] * sw[n] + bias) (+ residual): fp8 e4m3 operands, f32 accumulate
 static int linear_fp8(const uint8_t* A8, const float* sa, int64_t lda, const uint8_t* W8, const float* sw, const float* bias,
@@ -296,6 +320,7 @@ struct Plan {
   float *lse, *lse1, *attn_cls, *attn_diag, *out_last, *y; int32_t *idx_out, *idx_sa; void* refine_scratch;
   float *scores, *probs;
   float *omega, *qnorm, *knorm;
+  float *ln_slice, *ln_rows;                              // folded LayerNorm: slice statistics [R][D/64][2] written by the producing GEMM, (mean, rstd) [R][2]
   uint8_t* hmx;                                           // SG_PREC_FP8: MX block scales of h8 ([M/128][R][4] E8M0), written by the fc GEMM's epilogue
   uint8_t *x8, *h8; float *sx8, *sh8;                     // SG_PREC_FP8: quantised LN output / GELU output + per-row scales
   float *attn_avg, *sa_tmp, *sa_qk32, *sa_scores, *sa_probs;   // self-attention enhancement, mode='attention'; layer fusion
@@ -319,6 +344,8 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.ctx = b.take(R * d.width * e);
   p.hbuf = b.take(R * d.mlp_width * e);
   p.x8 = p.h8 = p.hmx = nullptr; p.sx8 = p.sh8 = nullptr;
+  p.ln_slice = p.ln_rows = nullptr;
+  if (c->hk && !c->fp8 && d.width % 64 == 0) { p.ln_slice = b.get<float>(R * (d.width / 64) * 2); p.ln_rows = b.get<float>(R * 2); }
   if (c->fp8) {
     p.x8 = (uint8_t*)b.take(R * d.width); p.sx8 = b.get<float>(R);
     p.h8 = (uint8_t*)b.take(R * d.mlp_width); p.sh8 = b.get<float>(R);
@@ -477,6 +504,10 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
       L.b_qkv = bb.get<float>(3 * D); L.b_out = bb.get<float>(D); L.b_fc = bb.get<float>(M); L.b_proj = bb.get<float>(D);
       L.ln1_g = bb.get<float>(D); L.ln1_b = bb.get<float>(D); L.ln2_g = bb.get<float>(D); L.ln2_b = bb.get<float>(D);
       L.w_qkv8 = L.w_fc8 = L.w_proj8 = nullptr; L.s_qkv = L.s_fc = L.s_proj = nullptr;
+      if (c->hk && !c->fp8) {
+        L.w_qkv_f = bb.take((size_t)3 * D * D * e); L.w_fc_f = bb.take((size_t)M * D * e);
+        L.c_qkv = bb.get<float>(3 * D); L.bf_qkv = bb.get<float>(3 * D); L.c_fc = bb.get<float>(M); L.bf_fc = bb.get<float>(M);
+      }
       if (c->fp8) {
         L.w_qkv8 = (uint8_t*)bb.take((size_t)3 * D * D); L.w_fc8 = (uint8_t*)bb.take((size_t)M * D); L.w_proj8 = (uint8_t*)bb.take((size_t)D * M);
         L.s_qkv = bb.get<float>(3 * D); L.s_fc = bb.get<float>(M); L.s_proj = bb.get<float>(D);
@@ -495,6 +526,7 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
 
 extern "C" void sg_destroy(sg_context* c) {
   if (!c) return;
+  for (auto& L : c->layers) { if (L.stage_qkv) (void)hipFree(L.stage_qkv); if (L.stage_fc) (void)hipFree(L.stage_fc); }
   if (c->arena) (void)hipFree(c->arena);
   delete c;
 }
@@ -534,11 +566,19 @@ extern "C" int sg_vit_set_tensor(sg_context* c, const char* name, const float* s
       if (find_layer_tensor(name + consumed, t)) {
         LayerW& L = c->layers[li];
         slot = 8 + li * 12 + t;
+        auto stage = [&](float*& dst, int64_t n) -> int {  // f32 copy of a weight the LayerNorm in front of it will be folded into
+          if (!L.w_qkv_f || numel != n) return SG_OK;
+          if (!dst) SG_HIP(hipMalloc((void**)&dst, (size_t)n * 4));
+          SG_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+          return SG_OK;
+        };
+        if (t <= 3 || (t >= 6 && t <= 9)) L.folded = false; // anything the folded operands are made from
         switch (t) {
           case 0: rc = copyf(L.ln1_g, D); break;
           case 1: rc = copyf(L.ln1_b, D); break;
           case 2: rc = packw(L.w_qkv, 3 * D, D, D);
                   if (rc == SG_OK && c->fp8) rc = quantize_rows_fp8(src, 0, D, L.w_qkv8, D, L.s_qkv, 3 * D, D, s);
+                  if (rc == SG_OK) rc = stage(L.stage_qkv, (int64_t)3 * D * D);
                   break;
           case 3: rc = copyf(L.b_qkv, 3 * D); break;
           case 4: rc = packw(L.w_out, D, D, D); break;
@@ -547,6 +587,7 @@ extern "C" int sg_vit_set_tensor(sg_context* c, const char* name, const float* s
           case 7: rc = copyf(L.ln2_b, D); break;
           case 8: rc = packw(L.w_fc, M, D, D);
                   if (rc == SG_OK && c->fp8) rc = quantize_rows_fp8(src, 0, D, L.w_fc8, D, L.s_fc, M, D, s);
+                  if (rc == SG_OK) rc = stage(L.stage_fc, (int64_t)M * D);
                   break;
           case 9: rc = copyf(L.b_fc, M); break;
           case 10: rc = packw(L.w_proj, D, M, M);
@@ -564,11 +605,27 @@ extern "C" int sg_vit_set_tensor(sg_context* c, const char* name, const float* s
   return SG_OK;
 }
 
-extern "C" int sg_vit_finalize(sg_context* c, sg_stream) {
+extern "C" int sg_vit_finalize(sg_context* c, sg_stream st) {
   SG_REQUIRE(c, "sg_vit_finalize: null context");
   int missing = 0;
   for (int i = 0; i < c->n_expected; ++i) if (!c->have[i]) ++missing;
   if (missing) return fail(SG_ERR_STATE, "sg_vit_finalize: %d of %d tensors were never set", missing, c->n_expected);
+  // fold ln_1 into the QKV weight and ln_2 into the fc weight of every block whose f32 weights are still staged; a block whose LayerNorm
+  // parameters were replaced without its weights keeps the explicit LayerNorm pass (folded == false)
+  DeviceGuard dg(c->device);
+  const int D = c->d.width, M = c->d.mlp_width;
+  bool any = false;
+  for (auto& L : c->layers) {
+    if (!L.w_qkv_f || L.folded || !L.stage_qkv || !L.stage_fc) continue;
+    SG_TRY(fold_ln_weight(L.stage_qkv, 3 * D, D, L.ln1_g, L.ln1_b, L.b_qkv, c->hk, L.w_qkv_f, L.c_qkv, L.bf_qkv, as_stream(st)));
+    SG_TRY(fold_ln_weight(L.stage_fc, M, D, L.ln2_g, L.ln2_b, L.b_fc, c->hk, L.w_fc_f, L.c_fc, L.bf_fc, as_stream(st)));
+    L.folded = true; any = true;
+  }
+  SG_HIP(hipStreamSynchronize(as_stream(st)));               // the staged f32 copies are freed below: their last readers (and writers) are on this stream
+  for (auto& L : c->layers) {
+    if (L.stage_qkv) { (void)hipFree(L.stage_qkv); L.stage_qkv = nullptr; }
+    if (L.stage_fc) { (void)hipFree(L.stage_fc); L.stage_fc = nullptr; }
+  }
   c->finalized = true;
   return SG_OK;
 }
@@ -579,7 +636,10 @@ extern "C" size_t sg_vit_workspace_bytes(const sg_context* c, int n_tiles, int g
   return plan(c, n_tiles, gh, gw, o, nullptr, true, p);
 }
 
-static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int64_t R, hipStream_t s) {
+// ln2_folded: the caller's out-projection GEMM already left x's 2-byte copy in p.xn and its slice statistics in p.ln_slice;
+// emit_next: the proj GEMM does the same for the x it produces (the next block's ln_1), *x16_valid reports it.
+static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int64_t R, hipStream_t s, bool ln2_folded = false,
+                     bool emit_next = false, bool* x16_valid = nullptr) {
   const sg_vit_desc& d = c->d;
   const int D = d.width, M = d.mlp_width;
   const int act = d.quick_gelu ? ACT_QUICK_GELU : ACT_GELU;
@@ -595,23 +655,42 @@ static int mlp_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
     SG_TRY(quantize_rows_fp8(p.hbuf, 1, M, p.h8, M, p.sh8, R, M, s));
     return linear_fp8(p.h8, p.sh8, M, L.w_proj8, L.s_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s);
   }
-  SG_TRY(layernorm(x, D, L.ln2_g, L.ln2_b, p.xn, D, c->hk, R, D, 1e-5f, s));
-  SG_TRY(linear(c->hk, p.xn, D, L.w_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
-  SG_TRY(linear(c->hk, p.hbuf, M, L.w_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s));
+  if (x16_valid) *x16_valid = false;
+  if (ln2_folded) {
+    SG_TRY(ln_stats_finalize(p.ln_slice, R, D, 1e-5f, p.ln_rows, s));
+    SG_TRY(linear_ln_consumer(c->hk, p.xn, D, L.w_fc_f, L.bf_fc, L.c_fc, p.ln_rows, p.hbuf, M, (int)R, M, D, act, s));
+  } else {
+    SG_TRY(layernorm(x, D, L.ln2_g, L.ln2_b, p.xn, D, c->hk, R, D, 1e-5f, s));
+    SG_TRY(linear(c->hk, p.xn, D, L.w_fc, L.b_fc, nullptr, p.hbuf, M, false, (int)R, M, D, act, s));
+  }
+  if (emit_next) {
+    SG_TRY(linear_ln_producer(c->hk, p.hbuf, M, L.w_proj, L.b_proj, x, x, D, p.xn, p.ln_slice, (int)R, D, M, s));
+    if (x16_valid) *x16_valid = true;
+  } else SG_TRY(linear(c->hk, p.hbuf, M, L.w_proj, L.b_proj, x, x, D, true, (int)R, D, M, ACT_NONE, s));
   return SG_OK;
 }
 
 // One ordinary residual block (reference open_clip/transformer.py:234-254), x updated in place.
 static int averaged_attention(sg_context* c, const Plan& p, int B, int N, hipStream_t s);
+// x16_valid (optional, in/out): in -- p.xn / p.ln_slice already hold the 2-byte copy and the slice statistics of THIS x (written by the
+// previous block's proj GEMM), so ln_1 is folded into the QKV GEMM; out -- the same for the x this block leaves behind.
 static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, int B, int N, bool stats, hipStream_t s, bool want_avg = false,
-                     bool causal = false) {
+                     bool causal = false, bool* x16_valid = nullptr) {
   const sg_vit_desc& d = c->d;
   const int D = d.width, H = d.heads;
   const int64_t R = (int64_t)B * N;
   AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1, p.omega, p.qnorm, p.knorm};
+  // LayerNorm folding: 2-byte modes, shapes that run on the persistent GEMM; cfg 34 (tuning) switches it off
+  const bool fold = c->hk && !c->fp8 && L.folded && p.ln_slice && R < (1ll << 31) && gemm_bf16_ln_fold_ok((int)R, D, D) && D % 256 == 0 &&
+                    get_gemm_config() != 34;
+  const bool ln1_folded = fold && x16_valid && *x16_valid;
+  if (x16_valid) *x16_valid = false;
   if (c->fp8 && p.x8 && L.w_qkv8) {
     SG_TRY(layernorm_fp8(x, D, L.ln1_g, L.ln1_b, p.x8, D, p.sx8, R, D, 1e-5f, s));
     SG_TRY(linear_fp8(p.x8, p.sx8, D, L.w_qkv8, L.s_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+  } else if (ln1_folded) {
+    SG_TRY(ln_stats_finalize(p.ln_slice, R, D, 1e-5f, p.ln_rows, s));
+    SG_TRY(linear_ln_consumer(c->hk, p.xn, D, L.w_qkv_f, L.bf_qkv, L.c_qkv, p.ln_rows, p.qkv, 3 * D, (int)R, 3 * D, D, ACT_NONE, s));
   } else {
     SG_TRY(layernorm(x, D, L.ln1_g, L.ln1_b, p.xn, D, c->hk, R, D, 1e-5f, s));
     SG_TRY(linear(c->hk, p.xn, D, L.w_qkv, L.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
@@ -621,8 +700,9 @@ static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
     SG_TRY(attention_stats(p.qkv, c->hk, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), p.attn_cls,
                            p.attn_diag, s));
   if (want_avg) SG_TRY(averaged_attention(c, p, B, N, s));
-  SG_TRY(linear(c->hk, p.ctx, D, L.w_out, L.b_out, x, x, D, true, (int)R, D, D, ACT_NONE, s));
-  return mlp_block(c, L, x, p, R, s);
+  if (fold) SG_TRY(linear_ln_producer(c->hk, p.ctx, D, L.w_out, L.b_out, x, x, D, p.xn, p.ln_slice, (int)R, D, D, s));
+  else SG_TRY(linear(c->hk, p.ctx, D, L.w_out, L.b_out, x, x, D, true, (int)R, D, D, ACT_NONE, s));
+  return mlp_block(c, L, x, p, R, s, fold, fold && x16_valid != nullptr, x16_valid);
 }
 
 static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan& p, int B, int N, hipStream_t s);
@@ -688,7 +768,8 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
   if (gem) {
     const int first = L - (o->gem_depth - 1);
     SG_REQUIRE(o->gem_depth >= 2 && first >= 0, "sg_vit_forward: gem_depth %d does not fit %d layers", o->gem_depth, L);
-    for (int i = 0; i < first; ++i) SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, false, s));
+    bool x16 = false;                                                 // p.xn / p.ln_slice describe p.x (folded LayerNorm hand-off between blocks)
+    for (int i = 0; i < first; ++i) SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, false, s, false, false, &x16));
     SG_TRY(gem_forward_tail(c, o, p, B, N, s));
     SG_TRY(layernorm(p.x_gem, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->hk, R, D, 1e-5f, s));
   } else {
@@ -697,11 +778,12 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     const bool want_stats = o->outlier_enabled != 0 && !fusion;       // transformer.py:609 (R6)
     const float lf = o->layer_fusion_lambda;
     const int64_t BNN = (int64_t)B * N * N;
+    bool x16 = false;                                                 // p.xn / p.ln_slice describe p.x (folded LayerNorm hand-off between blocks)
     for (int i = 0; i < L - 1; ++i) {
       if (i == mid && o->similarity_enabled)                          // normalised mid-layer patches (similarity_enhancement.py:49)
         SG_TRY(l2norm_rows(p.x + D, 0, (int64_t)N * D, D, n, p.xhat, c->hk, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));
       SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, want_stats && i == L - 2, s,
-                       fusion || (want_stats && i == L - 2 && o->selfattn_enabled && o->selfattn_mode == 1)));
+                       fusion || (want_stats && i == L - 2 && o->selfattn_enabled && o->selfattn_mode == 1), false, &x16));
       if (fusion) {                                                   // A_acc = lambda * A_acc + (1 - lambda) * A_l   (:601-607)
         if (i == 0) SG_HIP(hipMemcpyAsync(p.lf_acc, p.attn_avg, (size_t)BNN * 4, hipMemcpyDeviceToDevice, s));
         else SG_TRY(axpby(p.lf_acc, p.attn_avg, 1.0f - lf, lf, BNN, s));
@@ -1022,6 +1104,49 @@ extern "C" int sg_op_linear(const float* A, const float* W, const float* bias, c
   SG_TRY(pack_rows(A, M, K, K, a16, Kp, hk, s));
   SG_TRY(pack_rows(W, N, K, K, w16, Kp, hk, s));
   return linear(hk, a16, Kp, w16, bias, residual, C, N, true, M, N, Kp, act, s);
+}
+
+// x_new = x + A.W1^T + b1;  y = act(LayerNorm(x_new; gamma, beta).W2^T + b2)  -- the residual GEMM -> LayerNorm -> GEMM chain of a block
+// (out-proj -> ln_2 -> fc, proj -> ln_1 -> QKV), either with the LayerNorm as its own pass (fold = 0) or folded into the two GEMMs
+// (fold = 1: 2-byte copy + slice statistics out of the first epilogue, (mean, rstd) and the gamma-folded weight in the second).
+// 2-byte precisions only; M >= 1024, D >= 512, D % 64 == 0, N2 >= 512 with fold.  All operands f32 on the device.
+extern "C" size_t sg_op_ln_chain_scratch_bytes(int M, int K1, int D, int N2) {
+  const size_t K1p = align_up((size_t)K1, 64);
+  return align_up((size_t)M * K1p * 2, 256) + align_up((size_t)D * K1p * 2, 256) + align_up((size_t)M * D * 2, 256) + align_up((size_t)N2 * D * 2, 256) +
+         align_up((size_t)M * N2 * 2, 256) + align_up((size_t)M * (D / 64 + 1) * 8, 256) + align_up((size_t)M * 8, 256) + 2 * align_up((size_t)N2 * 4, 256) + 4096;
+}
+extern "C" int sg_op_ln_chain(const float* A, const float* W1, const float* b1, float* x, const float* gamma, const float* beta, const float* W2,
+                              const float* b2, float* y, int M, int K1, int D, int N2, int act, int precision, int fold, void* scratch,
+                              size_t scratch_bytes, sg_stream st) {
+  SG_REQUIRE(A && W1 && x && gamma && beta && W2 && y && scratch, "sg_op_ln_chain: null pointer");
+  SG_REQUIRE(precision == SG_PREC_BF16 || precision == SG_PREC_F16, "sg_op_ln_chain: 2-byte precisions only");
+  SG_REQUIRE(D % 64 == 0, "sg_op_ln_chain: D %% 64 != 0");
+  if (scratch_bytes < sg_op_ln_chain_scratch_bytes(M, K1, D, N2)) return fail(SG_ERR_STATE, "sg_op_ln_chain: scratch too small");
+  hipStream_t s = as_stream(st);
+  const int hk = precision == SG_PREC_F16 ? HK_F16 : HK_BF16;
+  const int K1p = (int)align_up(K1, 64);
+  Bump b(scratch, 0, false);
+  void* a16 = b.take((size_t)M * K1p * 2); void* w116 = b.take((size_t)D * K1p * 2); void* xn = b.take((size_t)M * D * 2);
+  void* w216 = b.take((size_t)N2 * D * 2); void* y16 = b.take((size_t)M * N2 * 2);
+  float* slice = b.get<float>((size_t)M * (D / 64) * 2); float* rows = b.get<float>((size_t)M * 2);
+  float* cvec = b.get<float>(N2); float* bf = b.get<float>(N2);
+  SG_TRY(pack_rows(A, M, K1, K1, a16, K1p, hk, s));
+  SG_TRY(pack_rows(W1, D, K1, K1, w116, K1p, hk, s));
+  if (fold) {
+    SG_TRY(linear_ln_producer(hk, a16, K1p, w116, b1, x, x, D, xn, slice, M, D, K1p, s));
+    SG_TRY(ln_stats_finalize(slice, M, D, 1e-5f, rows, s));
+    SG_TRY(fold_ln_weight(W2, N2, D, gamma, beta, b2, hk, w216, cvec, bf, s));
+    SG_TRY(linear_ln_consumer(hk, xn, D, w216, bf, cvec, rows, y16, N2, M, N2, D, act, s));
+  } else {
+    SG_TRY(linear(hk, a16, K1p, w116, b1, x, x, D, true, M, D, K1p, ACT_NONE, s));
+    SG_TRY(layernorm(x, D, gamma, beta, xn, D, hk, M, D, 1e-5f, s));
+    SG_TRY(pack_rows(W2, N2, D, D, w216, D, hk, s));
+    SG_TRY(linear(hk, xn, D, w216, b2, nullptr, y16, N2, false, M, N2, D, act, s));
+  }
+  const int64_t total = (int64_t)M * N2;
+  hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)y16, y, total, hk == HK_F16 ? 1 : 0);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
 }
 
 extern "C" size_t sg_op_attention_scratch_bytes(int B, int N, int D, int H, int precision) {

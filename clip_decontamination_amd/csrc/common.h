@@ -160,6 +160,13 @@ struct GemmBf16Args {
   //   c_mx      : write C as e4m3 bytes [M, N] with block scales c_mx_scale in the same [N/128][M][4] layout (C / c_is_bf16 ignored):
   //               the next linear's MX operand straight out of this epilogue, no separate quantisation pass
   const uint8_t* a_mx; uint8_t* c_mx; uint8_t* c_mx_scale;
+  // LayerNorm folded into the two GEMMs either side of it (persistent kernel only, batch 1; capi.hip std_block).  LN(x).W^T + b =
+  // rstd (x.W'^T - mean c) + b' with W' = gamma o W, c[n] = sum_k W'[n][k], b' = b + W.beta, so the normalisation never runs as a pass:
+  //   producer (f32 C, with or without residual): copy16 / ld16 = a 2-byte copy of the finished rows (the next GEMM's A operand),
+  //     row_stats [M][N/64][2] = (sum, centred sum of squares) of every 64-column slice of a finished row
+  //   consumer: ln_stats [M][2] = (mean, rstd) per row, ln_c = c; bias = b'
+  void* copy16; int64_t ld16; float* row_stats;
+  const float* ln_stats; const float* ln_c;
   // persistent kernel only: row-dot epilogue.  With v = alpha * acc + bias and r = residual, NOTHING is stored to C; instead
   // rowdot[m * rowdot_ld + n / 64] = sum over the 64 columns [n, n + 64) of v * (2 r + v)  (= |r + v|^2 - |r|^2 of that column slice):
   // the JBU tail needs only the norm of x + 0.1 * conv1x1(x), never the C x S^2 map itself.  f32 residual required.
@@ -172,6 +179,7 @@ struct GemmBf16Args {
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
 int get_gemm_config();
+bool gemm_bf16_ln_fold_ok(int M, int N, int K);   // the shapes whose dispatch reaches the persistent kernel (the folded-LayerNorm epilogues live there)
 void set_gemm_config(int c);   // tuning hook (per calling thread): -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
 
 // f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];

@@ -807,9 +807,16 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 //        A(s+2), W(s+2), A(s+3) = 6), group 1 after READ(s) (tiles s+2, s+3 = 8); both before the barrier closing slot 2s+1.
 //   tile end: group 0 takes one extra barrier (both groups are then past every read of the tile's last K tile), every wave runs the
 //        coalescing epilogue through a private patch inside the just-consumed ring slot, one barrier, group 1 re-staggers.
-template <int MI, int NI, bool F16>
-__device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
+// LN = the consumer side of a folded LayerNorm (2-byte output only): its own instantiation, so that its per-row / per-column factors and
+// the other form's residual pipeline do not hold registers at the same time.
+// MODE 1 = the consumer side of a folded LayerNorm (2-byte output only), MODE 2 = the producer side (f32 output + 2-byte copy + slice
+// statistics): their own instantiations, so that the per-row / per-column factors of the one, the statistics of the other and the plain
+// form's deeper residual pipeline never hold registers at the same time.
+template <int MI, int NI, bool F16, int MODE = 0>
+__device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16_rt, int z, int row0,
                                                 int col0, float* patch, int lane) {
+  constexpr bool LN = MODE == 1, PROD = MODE == 2;
+  const int c_bf16 = LN ? 1 : (PROD ? 0 : c_bf16_rt);
   constexpr int TN = NI * 16, LDP = TN + 4;
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
   float4 bias4[NI];
@@ -819,9 +826,24 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
     bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias && n + 3 < a.N) bias4[j] = *reinterpret_cast<const float4*>(a.bias + n);
   }
+  // folded LayerNorm, consumer side (wave-uniform): per-row (mean, rstd) of the 8 rows this lane's accumulators belong to, per-column c
+  float4 lnc4[LN ? NI : 1];
+  auto ln_row = [&](int i) -> float2 {                     // (mean, rstd) of the row this lane's accumulators of strip pair i belong to
+    int m = row0 + i * 16 + (lane & 15); m = m < a.M ? m : a.M - 1;
+    return *reinterpret_cast<const float2*>(a.ln_stats + 2 * (int64_t)m);
+  };
+  float2 ln_cur = make_float2(0.f, 1.f), ln_nxt = ln_cur;  // fetched two strip pairs ahead
+  if constexpr (LN) {
+    ln_cur = ln_row(0); ln_nxt = ln_row(1);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = col0 + j * 16 + (lane >> 4) * 4;
+      lnc4[j] = (n + 3 < a.N) ? *reinterpret_cast<const float4*>(a.ln_c + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   // f32 output with residual: the residual of strip t + RD is requested while strip t goes through the patch, so RD strips of HBM
   // latency are in flight per wave instead of one dependent load -> add -> store chain per strip (addresses clamped, stores guarded)
-  constexpr int RD = 5;
+  constexpr int RD = PROD ? 4 : 5;
   constexpr int LPRF = TN / 4, RPPF = 64 / LPRF, NPASS = 8 / RPPF;
   float4 rbuf[RD][NPASS];
   auto fetch_res = [&](int t, float4 (&dst)[NPASS]) {
@@ -837,7 +859,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       } else dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
     }
   };
-  const bool pipe_res = res != nullptr && !c_bf16;
+  const bool pipe_res = !LN && res != nullptr && !c_bf16;
   if (pipe_res) {
 #pragma unroll
     for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
@@ -845,10 +867,17 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float4 v4[NI];
+    const float2 ln_use = ln_cur;
+    if constexpr (LN) { ln_cur = ln_nxt; if (i + 2 < MI) ln_nxt = ln_row(i + 2); }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       float v[4] = {acc[i][j][0] * a.alpha + bias4[j].x, acc[i][j][1] * a.alpha + bias4[j].y, acc[i][j][2] * a.alpha + bias4[j].z,
                     acc[i][j][3] * a.alpha + bias4[j].w};
+      if constexpr (LN) {                                  // rstd (x.W'^T - mean c) + b'
+        const float mu = ln_use.x, rs = ln_use.y;
+        v[0] = (acc[i][j][0] - mu * lnc4[j].x) * rs + bias4[j].x; v[1] = (acc[i][j][1] - mu * lnc4[j].y) * rs + bias4[j].y;
+        v[2] = (acc[i][j][2] - mu * lnc4[j].z) * rs + bias4[j].z; v[3] = (acc[i][j][3] - mu * lnc4[j].w) * rs + bias4[j].w;
+      }
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -864,6 +893,10 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
 #pragma unroll
         for (int j = 0; j < NI; ++j) *reinterpret_cast<float4*>(patch + (lane & 7) * LDP + j * 16 + (lane >> 4) * 4) = v4[j];
       }
+      // Keep the patch READS below out of the half-wave block above: with the output type a compile-time constant (MODE 1 / 2) hipcc 7.2
+      // sank the first ds_read_b128 of a strip into the exec-masked write block, so the other half of the wave kept the previous strip's
+      // values (found as rows 8-11, 16-19, ... of the producer form carrying the GEMM part of rows 0-3, 8-11, ...).
+      if constexpr (MODE != 0) asm volatile("" ::: "memory");
       const int rbase = row0 + i * 16 + hh * 8;
       if (c_bf16) {                                        // 8 lanes x 16 B per row: one instruction stores the whole strip
         constexpr int LPR = TN / 8;
@@ -898,6 +931,30 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           }
           if (r < 8 && m < a.M && n < a.N)
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = x;
+          if constexpr (PROD) *reinterpret_cast<float4*>(patch + r * LDP + cq) = x;   // the finished values go back into the patch (same lane, same place)
+        }
+        if constexpr (PROD) {
+          // folded LayerNorm, producer side: the strip's finished rows are read back in the 2-byte form's layout (8 lanes x 8 columns per row,
+          // 8 rows per instruction): one 16-byte store per lane for the next GEMM's operand, and the slice statistics from 3 + 3 shuffles
+          static_assert(TN == 64, "row statistics are kept per 64-column slice");
+          asm volatile("" ::: "memory");
+          const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+          const int m8 = rbase + r8, n8 = col0 + c8;
+          const float4 y0 = *reinterpret_cast<const float4*>(patch + r8 * LDP + c8);
+          const float4 y1 = *reinterpret_cast<const float4*>(patch + r8 * LDP + c8 + 4);
+          if (m8 < a.M && n8 < a.N) {
+            uint4 o; o.x = pack_half2<F16>(y0.x, y0.y); o.y = pack_half2<F16>(y0.z, y0.w); o.z = pack_half2<F16>(y1.x, y1.y); o.w = pack_half2<F16>(y1.z, y1.w);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.copy16) + (int64_t)m8 * a.ld16 + n8) = o;
+          }
+          float sm = ((y0.x + y0.y) + (y0.z + y0.w)) + ((y1.x + y1.y) + (y1.z + y1.w));
+          sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+          const float mu = sm * (1.0f / 64.0f);
+          const float e0 = y0.x - mu, e1 = y0.y - mu, e2 = y0.z - mu, e3 = y0.w - mu, e4 = y1.x - mu, e5 = y1.y - mu, e6 = y1.z - mu, e7 = y1.w - mu;
+          float sq = ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7));
+          sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+          if ((lane & 7) == 0 && m8 < a.M)
+            *reinterpret_cast<float2*>(a.row_stats + ((int64_t)m8 * (a.N >> 6) + (col0 >> 6)) * 2) = make_float2(sm, sq);
+          asm volatile("" ::: "memory");
         }
         if (pipe_res && t + RD < 2 * MI) fetch_res(t + RD, rbuf[t % RD]);
       }
@@ -905,7 +962,9 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
   }
 }
 
-template <bool F16>
+// EPI: 0 = the plain epilogue, 1 / 2 = the consumer / producer side of a folded LayerNorm (epilogue_store8's MODE): separate kernels, so
+// that the plain one keeps exactly the register allocation it was tuned with.
+template <bool F16, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act, int c_bf16) {
   constexpr int PBM = 256, PBN = 256, KT32 = 32;
   constexpr int TILE_B = (PBM + PBN) * KT32 * 2;             // 32 KiB per ring slot
@@ -1036,7 +1095,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
     if (g == 0) SG_PS_SYNC();                               // align: every read of this tile's last K tile has retired
     {
       float* patch = reinterpret_cast<float*>(lds + ((s - 1) & 3) * TILE_B) + wave * 576;   // 8 rows x 68 floats (+pad) per wave
-      epilogue_store8<8, 4, F16>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
+      epilogue_store8<8, 4, F16, EPI>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);
@@ -1319,7 +1378,9 @@ static int launch_fp8_persist(const GemmBf16Args& a, hipStream_t s) {
 
 static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
-  auto kern = a.f16 ? gemm_bf16_persist<true> : gemm_bf16_persist<false>;
+  auto kern = a.ln_stats ? (a.f16 ? gemm_bf16_persist<true, 1> : gemm_bf16_persist<false, 1>)
+            : a.copy16 ? (a.f16 ? gemm_bf16_persist<true, 2> : gemm_bf16_persist<false, 2>)
+                       : (a.f16 ? gemm_bf16_persist<true, 0> : gemm_bf16_persist<false, 0>);
   SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int n_cu = device_cu_count();
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
@@ -1343,6 +1404,7 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
 
 static thread_local int g_gemm_config = -1;                // -1 = pick per shape (tuning override, per calling thread)
 int get_gemm_config() { return g_gemm_config; }
+bool gemm_bf16_ln_fold_ok(int M, int N, int K) { return M >= 1024 && N >= 512 && N % 64 == 0 && K % 32 == 0 && K / 32 >= 4; }
 void set_gemm_config(int c) {
   if (c >= 1000) { g_gemm_order = c - 1001; return; }      // 1000 -> -1 (automatic), 1001 -> 0 (raster), 1001 + v -> N-group size v
   g_gemm_config = c;
@@ -1419,8 +1481,15 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   if (a.rowdot)
     SG_REQUIRE(vec && a.residual && !a.c_is_bf16 && a.batch == 1 && a.M >= 1024 && a.N >= 512 && a.N % 64 == 0 && a.K / 32 >= 4,
                "gemm_bf16: the row-dot epilogue needs the persistent kernel (M >= 1024, N >= 512, N %% 64 == 0), an f32 residual and batch 1");
+  const bool ln_fold = a.copy16 != nullptr || a.ln_stats != nullptr;
+  if (ln_fold) {
+    SG_REQUIRE(vec && a.batch == 1 && gemm_bf16_ln_fold_ok(a.M, a.N, a.K), "gemm_bf16: the folded-LayerNorm epilogues need the persistent kernel (M >= 1024, N >= 512, batch 1)");
+    if (a.copy16) SG_REQUIRE(a.row_stats && !a.c_is_bf16 && !a.rowdot && a.N % 64 == 0 && a.ld16 % 4 == 0 && ((((uintptr_t)a.copy16) & 7) == 0), "gemm_bf16: copy16 needs row_stats, an f32 C and N %% 64 == 0");
+    if (a.ln_stats) SG_REQUIRE(a.ln_c && a.alpha == 1.f && a.c_is_bf16 && !a.residual && !a.rowdot && ((((uintptr_t)a.ln_c) & 15) == 0) && ((((uintptr_t)a.ln_stats) & 7) == 0), "gemm_bf16: ln_stats needs ln_c and alpha 1");
+  }
   int cfg = g_gemm_config;
-  if (a.rowdot) cfg = 30;
+  if (cfg == 33 || cfg == 34) cfg = -1;                    // tuning codes read by capi.hip (MX hand-off / LayerNorm folding off), not tile configurations
+  if (a.rowdot || ln_fold) cfg = 30;
   if (cfg < 0 || a.f16) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
   if (cfg > 0) {
     const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? PROF_GEMM_PERSIST : PROF_GEMM_BF16;

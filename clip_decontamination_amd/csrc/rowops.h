@@ -15,6 +15,13 @@ int embed_assemble(const float* patches, int64_t ldp, const float* cls_emb, cons
                    const float* beta, float* x, int B, int N, int D, float eps, hipStream_t s);
 int posembed_resize(const float* pos, int g0, int D, int gh, int gw, int antialias, float* out, hipStream_t s);
 int pack_rows(const float* src, int64_t rows, int cols, int64_t ld_src, void* dst, int cols_pad, int to_bf16, hipStream_t s);
+// LayerNorm folded into its neighbouring GEMMs (GemmBf16Args::copy16 / ln_stats):
+//   ln_stats_finalize: the producer's slice statistics [rows][D/64][2] (sum, centred sum of squares) -> (mean, rstd) per row [rows][2]
+//   fold_ln_weight:    W' = gamma o W packed in the compute dtype, c[n] = sum_k W'[n][k] (of the ROUNDED W', so that x.W'^T - mean c cancels
+//                      exactly), b'[n] = b[n] + sum_k beta[k] W[n][k]
+int ln_stats_finalize(const float* slice_stats, int64_t rows, int D, float eps, float* mean_rstd, hipStream_t s);
+int fold_ln_weight(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, int hk, void* Wp, float* c,
+                   float* bias_f, hipStream_t s);
 int transpose_pack(const float* src, int rows, int cols, void* dst, int to_bf16, hipStream_t s);
 int l2norm_rows(const void* x, int x_bf16, int64_t so, int64_t si, int inner, void* y, int y_bf16, int64_t yo, int64_t yi,
                 int64_t rows, int D, float eps, hipStream_t s);

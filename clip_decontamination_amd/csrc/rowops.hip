@@ -319,6 +319,60 @@ int pack_rows(const float* src, int64_t rows, int cols, int64_t ld_src, void* ds
   return SG_OK;
 }
 
+// ---- LayerNorm folded into the neighbouring GEMMs -----------------------------------------------------------------------------------
+// Chan's pairwise combination of the per-slice (sum, centred sum of squares): exact to f32 rounding whatever the mean is.
+// 16 lanes per row (one 64-column slice each when D = 1024; they stride over more), coalesced 8-byte loads.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ st, int64_t rows, int S, float eps, float* __restrict__ out) {
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  const bool live = r < rows;
+  const float2* p = reinterpret_cast<const float2*>(st) + (live ? r : 0) * S;
+  float tot = 0.f;
+  for (int i = l; i < S; i += 16) tot += p[i].x;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) tot += __shfl_xor(tot, o, 64);
+  const float mean = tot / (float)(S * 64);
+  float m2 = 0.f;
+  for (int i = l; i < S; i += 16) { const float d = p[i].x * (1.0f / 64.0f) - mean; m2 += p[i].y + 64.0f * d * d; }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+  if (live && l == 0) reinterpret_cast<float2*>(out)[r] = make_float2(mean, 1.0f / sqrtf(m2 / (float)(S * 64) + eps));
+}
+int ln_stats_finalize(const float* slice_stats, int64_t rows, int D, float eps, float* mean_rstd, hipStream_t s) {
+  SG_REQUIRE(D % 64 == 0 && rows > 0, "ln_stats_finalize: D=%d must be a multiple of 64", D);
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, s, slice_stats, rows, D / 64, eps, mean_rstd);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+// one wave per output channel n
+template <typename OutT>
+__global__ __launch_bounds__(256) void fold_ln_weight_kernel(const float* __restrict__ W, int N, int K, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias, OutT* __restrict__ Wp,
+                                                             float* __restrict__ c, float* __restrict__ bias_f) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float cs = 0.f, bs = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(int64_t)n * K + k];
+    const OutT h = from_f32<OutT>(w * gamma[k]);
+    Wp[(int64_t)n * K + k] = h;
+    cs += to_f32<OutT>(h);
+    bs += beta[k] * w;
+  }
+  cs = wave_sum(cs); bs = wave_sum(bs);
+  if (lane == 0) { c[n] = cs; bias_f[n] = (bias ? bias[n] : 0.f) + bs; }
+}
+int fold_ln_weight(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, int hk, void* Wp, float* c,
+                   float* bias_f, hipStream_t s) {
+  SG_REQUIRE(hk == HK_BF16 || hk == HK_F16, "fold_ln_weight: 2-byte compute dtypes only");
+  const dim3 grid((unsigned)cdiv(N, 4));
+  if (hk == HK_F16) hipLaunchKernelGGL(fold_ln_weight_kernel<f16_t>, grid, dim3(256), 0, s, W, N, K, gamma, beta, bias, (f16_t*)Wp, c, bias_f);
+  else hipLaunchKernelGGL(fold_ln_weight_kernel<bf16_t>, grid, dim3(256), 0, s, W, N, K, gamma, beta, bias, (bf16_t*)Wp, c, bias_f);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
 // transpose-pack: dst[c][r] = src[r][c]   (proj [D,E] -> W[E,D] so `x @ proj` becomes a W[N,K]^T GEMM)
 __global__ void transpose_pack_kernel(const float* __restrict__ src, int rows, int cols, void* __restrict__ dst, int to_bf16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -104,6 +104,24 @@ def quantize_rows_fp8(x):
 
 
 @on_tensor_device
+def ln_chain(A, W1, b1, x, gamma, beta, W2, b2, act: int = 0, precision="bf16", fold: bool = True):
+    """x_new = x + A @ W1^T + b1;  y = act(LayerNorm(x_new) @ W2^T + b2): the residual GEMM -> LayerNorm -> GEMM chain of a block, with the
+    LayerNorm folded into the two GEMMs (fold) or as its own pass.  Returns (x_new, y), both f32."""
+    lib = _lib.load()
+    A, W1, b1, gamma, beta, W2, b2 = (_f32(t) for t in (A, W1, b1, gamma, beta, W2, b2))
+    x = _f32(x).clone()
+    M, K1 = A.shape
+    D, N2 = W1.shape[0], W2.shape[0]
+    y = torch.empty(M, N2, dtype=torch.float32, device=A.device)
+    nbytes = lib.sg_op_ln_chain_scratch_bytes(M, K1, D, N2)
+    buf = scratch(nbytes, A.device)
+    sp, sn = _aligned(buf)
+    check(lib.sg_op_ln_chain(ptr(A), ptr(W1), ptr(b1), ptr(x), ptr(gamma), ptr(beta), ptr(W2), ptr(b2), ptr(y), M, K1, D, N2, act,
+                             precision_id(precision), int(fold), sp, sn, stream_ptr()), "sg_op_ln_chain")
+    return x, y
+
+
+@on_tensor_device
 def gemm_fp8_mx(a8, w8, sw, sa=None, a_mx=None, bias=None, residual=None, act: int = 0, out_bf16: bool = False, mx_out: bool = False):
     """The MXFP8 forms of the fp8 GEMM (include/segearth_hip.h: sg_gemm_fp8_mx_raw) on caller-quantised operands.  a8 [M,K] u8 with
     either per-row scales `sa` [M] or E8M0 block scales `a_mx` [K/128, M, 4] u8; w8 [N,K] u8 with per-row scales sw [N].

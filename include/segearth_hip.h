@@ -212,6 +212,16 @@ int sg_similarity_map(const float* patches, int64_t batch_stride, int ld, int B,
  * `precision`.  act: 0 none, 1 QuickGELU, 2 erf GELU. */
 int sg_op_linear(const float* A, const float* W, const float* bias, const float* residual, float* C,
                  int M, int N, int K, int act, int precision, void* scratch, size_t scratch_bytes, sg_stream s);
+/* The residual GEMM -> LayerNorm -> GEMM chain of a transformer block (reference open_clip/transformer.py:234-254: x = x + out_proj(attn);
+ * mlp(ln_2(x)), and the next block's attention(ln_1(x))):  x <- x + A.W1^T + b1 (in place),  y = act(LayerNorm(x; gamma, beta).W2^T + b2).
+ * fold = 0 runs the LayerNorm as its own pass; fold = 1 is what the towers do in the 2-byte modes: the first GEMM's epilogue also writes the
+ * 2-byte copy of x and per-64-column (sum, centred sum of squares), the second GEMM runs on that copy with W' = gamma o W2 and applies
+ * rstd (acc - mean c) + b' in its epilogue (c = row sums of W', b' = b2 + W2.beta) -- no pass over x in between.
+ * precision: SG_PREC_BF16 / SG_PREC_F16; fold needs M >= 1024, D >= 512, D % 64 == 0, N2 >= 512.  All pointers are f32 device memory. */
+size_t sg_op_ln_chain_scratch_bytes(int M, int K1, int D, int N2);
+int sg_op_ln_chain(const float* A, const float* W1, const float* b1, float* x, const float* gamma, const float* beta, const float* W2,
+                   const float* b2, float* y, int M, int K1, int D, int N2, int act, int precision, int fold, void* scratch,
+                   size_t scratch_bytes, sg_stream s);
 /* bf16 GEMM on caller-packed operands: A [M,K], W [N,K] bf16 (K % 64 == 0), C bf16 or f32 */
 int sg_gemm_bf16_raw(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                      int act, int c_is_bf16, sg_stream s);

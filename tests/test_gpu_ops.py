@@ -507,3 +507,41 @@ def test_new_entry_points_reject_bad_arguments(ops):
     assert lib.sg_render_maps(None, None, None, 3, 4, 4, P(buf), None, None) != 0                                                   # mask without labels
     assert lib.sg_gemm_fp8_raw(P(buf), P(cls), P(buf), P(cls), None, None, P(x), 4, 8, 64, 0, 0, None) != 0                          # K % 128
     assert b"128" in lib.sg_last_error()
+
+
+# ---- LayerNorm folded into its neighbouring GEMMs (sg_op_ln_chain; the towers' 2-byte modes) -----------------------------------------
+def _ln_chain_ref(A, W1, b1, x, g, be, W2, b2, act):
+    xn = x.double() + A.double() @ W1.double().T + b1.double()
+    y = torch.nn.functional.layer_norm(xn, (xn.shape[1],), g.double(), be.double(), 1e-5) @ W2.double().T + b2.double()
+    if act == 1:
+        y = y * torch.sigmoid(1.702 * y)
+    elif act == 2:
+        y = torch.nn.functional.gelu(y)
+    return xn.float(), y.float()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K1,D,N2,act,mean_shift", [(1370, 1024, 1024, 3072, 0, 0.0), (2055, 4096, 1024, 4096, 1, 0.0),
+                                                      (1200, 768, 768, 3072, 2, 3.0), (1024, 512, 512, 512, 0, -1.0)])
+def test_ln_chain_folded_matches_unfolded_and_f64(prec, M, K1, D, N2, act, mean_shift):
+    """Residual GEMM -> LayerNorm -> GEMM with the LayerNorm folded into the two epilogues: the f32 residual stream must equal the unfolded
+    path's bit for bit (same GEMM), y must be as close to the f64 result as the unfolded path's (2-byte operands either way) -- also when
+    the rows have a mean several standard deviations away from 0 (the case the centred statistics and the exact mean * c cancellation are for)."""
+    from clip_decontamination_amd import ops
+    g = lambda *sh, seed, sc=1.0: (torch.from_numpy(np.random.default_rng(seed).standard_normal(sh).astype(np.float32)) * sc).to(DEV)
+    A, W1, b1 = g(M, K1, seed=1), g(D, K1, seed=2, sc=K1 ** -0.5), g(D, seed=3, sc=0.1)
+    x = g(M, D, seed=4) * torch.logspace(-1, 1, M, device=DEV).view(M, 1) + mean_shift
+    x[:, 7] += 20.0                                            # one outlier channel, as real residual streams have
+    gamma, beta = 1.0 + 0.3 * g(D, seed=5), 0.2 * g(D, seed=6)
+    W2, b2 = g(N2, D, seed=7, sc=D ** -0.5), g(N2, seed=8, sc=0.1)
+    xf, yf = ops.ln_chain(A, W1, b1, x, gamma, beta, W2, b2, act, prec, fold=True)
+    xu, yu = ops.ln_chain(A, W1, b1, x, gamma, beta, W2, b2, act, prec, fold=False)
+    xr, yr = _ln_chain_ref(A, W1, b1, x, gamma, beta, W2, b2, act)
+    assert torch.equal(xf, xu)                                  # the residual stream itself is untouched by the folding
+    assert (xf - xr).abs().max().item() < 2e-2 * xr.abs().max().item()
+    ef = (yf - yr).abs()
+    eu = (yu - yr).abs()
+    scale = yr.abs().max().item()
+    print(f"{prec} M={M} D={D} N2={N2}: folded max {ef.max().item():.3e} mean {ef.mean().item():.3e} | unfolded max {eu.max().item():.3e} mean {eu.mean().item():.3e} (|y| max {scale:.2f})")
+    assert ef.mean().item() < 1.5 * eu.mean().item() + 1e-6
+    assert ef.max().item() < 2.5 * eu.max().item() + 1e-3 * scale
