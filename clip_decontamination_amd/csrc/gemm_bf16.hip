@@ -896,15 +896,16 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       // Keep the patch READS below out of the half-wave block above: with the output type a compile-time constant (MODE 1 / 2) hipcc 7.2
       // sank the first ds_read_b128 of a strip into the exec-masked write block, so the other half of the wave kept the previous strip's
       // values (found as rows 8-11, 16-19, ... of the producer form carrying the GEMM part of rows 0-3, 8-11, ...).
-      if constexpr (MODE != 0) asm volatile("" ::: "memory");
+      int pofs = 0;                                        // an opaque 0 added to every patch read address below: the reads depend on a
+      if constexpr (MODE != 0) asm volatile("" : "+v"(pofs));   // statement that follows the block, so they cannot be moved into it
       const int rbase = row0 + i * 16 + hh * 8;
       if (c_bf16) {                                        // 8 lanes x 16 B per row: one instruction stores the whole strip
         constexpr int LPR = TN / 8;
         const int r = lane / LPR, cq = (lane % LPR) * 8;
         const int m = rbase + r, n = col0 + cq;
         if (r < 8 && m < a.M && n < a.N) {
-          const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
-          const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
+          const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + pofs);
+          const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4 + pofs);
           uint4 o; o.x = pack_half2<F16>(x0.x, x0.y); o.y = pack_half2<F16>(x0.z, x0.w); o.z = pack_half2<F16>(x1.x, x1.y); o.w = pack_half2<F16>(x1.z, x1.w);
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
         }
@@ -916,7 +917,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
         for (int r0 = 0; r0 < 8; r0 += RPP) {
           const int r = r0 + lane / LPR, cq = (lane % LPR) * 4;
           const int m = rbase + r, n = col0 + cq;
-          float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq + pofs);
           if (a.rowdot) {                                    // row-dot epilogue (wave-uniform): v * (2 r + v) summed over this wave's 64 columns
             const float4 rr = rbuf[t % RD][r0 / RPP];
             float d = x.x * (2.f * rr.x + x.x) + x.y * (2.f * rr.y + x.y) + x.z * (2.f * rr.z + x.z) + x.w * (2.f * rr.w + x.w);
@@ -933,11 +934,11 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = x;
           if constexpr (PROD) *reinterpret_cast<float4*>(patch + r * LDP + cq) = x;   // the finished values go back into the patch (same lane, same place)
         }
+        if (pipe_res && t + RD < 2 * MI) fetch_res(t + RD, rbuf[t % RD]);
         if constexpr (PROD) {
           // folded LayerNorm, producer side: the strip's finished rows are read back in the 2-byte form's layout (8 lanes x 8 columns per row,
           // 8 rows per instruction): one 16-byte store per lane for the next GEMM's operand, and the slice statistics from 3 + 3 shuffles
           static_assert(TN == 64, "row statistics are kept per 64-column slice");
-          asm volatile("" ::: "memory");
           const int r8 = lane >> 3, c8 = (lane & 7) * 8;
           const int m8 = rbase + r8, n8 = col0 + c8;
           const float4 y0 = *reinterpret_cast<const float4*>(patch + r8 * LDP + c8);
@@ -954,9 +955,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
           if ((lane & 7) == 0 && m8 < a.M)
             *reinterpret_cast<float2*>(a.row_stats + ((int64_t)m8 * (a.N >> 6) + (col0 >> 6)) * 2) = make_float2(sm, sq);
-          asm volatile("" ::: "memory");
         }
-        if (pipe_res && t + RD < 2 * MI) fetch_res(t + RD, rbuf[t % RD]);
       }
     }
   }

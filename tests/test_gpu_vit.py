@@ -264,3 +264,40 @@ def test_layer_fusion_multi_head_vs_oracle(prec):
     a = net.encode_image(img.to(DEV), "SegEarth", True, output_cls_token=True, apply_layer_fusion=True)[1]
     b = net.encode_image(img.to(DEV), "SegEarth", True, output_cls_token=True)[1]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_folded_layernorm_tower_vs_separate_pass(prec):
+    """ViT-B/16, 8 tiles (R = 1576 rows: the persistent GEMM path, where ln_1 / ln_2 are folded into the QKV / fc GEMMs): the tower with the
+    folding switched off (tuning code 34: LayerNorm as its own pass, as in round 1) must agree with the default to 2-byte rounding, and a
+    block whose LayerNorm parameters are replaced AFTER sg_vit_finalize (no staged f32 weight to re-fold from) falls back to the pass."""
+    import ctypes as C
+    from clip_decontamination_amd import _lib
+    lib = _lib.load()
+    cfg, net = tower("ViT-B-16", prec)
+    img = torch.from_numpy(Wt.normalize_tiles(Wt.make_tiles_u8(8, 224, seed=77, smooth=True))).to(DEV)
+    cls_f, tok_f = net.encode_image(img, "SegEarth", True, output_cls_token=True)
+    lib.sg_set_gemm_config(34)
+    try:
+        cls_u, tok_u = net.encode_image(img, "SegEarth", True, output_cls_token=True)
+    finally:
+        lib.sg_set_gemm_config(-1)
+    scale = tok_u.abs().max().item()
+    d = (tok_f - tok_u).abs().max().item()
+    print(f"[{prec}] folded vs separate LayerNorm: max|dtoken| = {d:.3e} (|token| max {scale:.2f})")
+    assert d < HALF_TOL[prec]["tiny_tokens"] * scale
+    assert not torch.equal(tok_f, tok_u)                      # the two paths really are different code
+    # replace one block's ln_2 scale after finalize: that block must leave the folded path (its folded weight would be stale)
+    v = net.visual
+    g = (torch.from_numpy(Wt.make_vit_weights(cfg, seed=0)["transformer.resblocks.3.ln_2.weight"]) * 1.5).to(DEV)
+    _lib.check(lib.sg_vit_set_tensor(v._ctx, b"transformer.resblocks.3.ln_2.weight", C.c_void_p(g.data_ptr()), g.numel(), None), "set_tensor")
+    _lib.check(lib.sg_vit_finalize(v._ctx, None), "finalize")
+    torch.cuda.synchronize()
+    _, tok_a = net.encode_image(img, "SegEarth", True, output_cls_token=True)
+    lib.sg_set_gemm_config(34)
+    try:
+        _, tok_b = net.encode_image(img, "SegEarth", True, output_cls_token=True)
+    finally:
+        lib.sg_set_gemm_config(-1)
+    assert (tok_a - tok_b).abs().max().item() < HALF_TOL[prec]["tiny_tokens"] * scale      # the new scale is honoured on both paths
+    assert (tok_a - tok_f).abs().max().item() > 1e-3 * scale                                # and it did change the result
