@@ -264,7 +264,11 @@ def main():
     tiles_total = len(wins) * args.steps
     value = tiles_total * TILE * TILE / dt / 1e6
     if rank == 0:
-        g_ms, g_fl, g_n, g_drop = prof(3)                  # gemm_bf16_persist: the dominant kernel (every large ViT linear)
+        g_ms, g_fl, g_n, g_drop = prof(3)                  # gemm_bf16_persist: the dominant kernel (every large ViT linear), all instantiations
+        c_ms, c_fl, c_n, _ = prof(5)                       # ... of which: epilogue applies a folded LayerNorm (QKV, fc)
+        p_ms, p_fl, p_n, _ = prof(6)                       # ... of which: epilogue also emits the next LayerNorm's operand + statistics (out-proj, proj)
+        def _part(ms, fl, n):
+            return {"launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2), "achieved": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0}
         o_ms, o_fl, o_n, _ = prof(0)                       # the remaining bf16 GEMM launches (patch embed, proj, similarity map)
         a_ms, a_fl, a_n, _ = prof(1)
         f_ms, f_fl, f_n, _ = prof(4)                       # fp8 GEMM launches (only with --precision fp8)
@@ -286,6 +290,10 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic()[0], "traffic_note": pmc_traffic()[1],
                          "launches": g_n, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
                          "algorithmic_gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3), "events_dropped": g_drop,
+                         "by_epilogue": {"note": "the same kernel's three instantiations; the folded ones carry 46 of the step's 48 LayerNorm passes "
+                                                 "(the separate pass was 220 us per LayerNorm), so their FLOP rate is not comparable with round 1's",
+                                         "plain": _part(g_ms - c_ms - p_ms, g_fl - c_fl - p_fl, g_n - c_n - p_n),
+                                         "folded_ln_consumer": _part(c_ms, c_fl, c_n), "folded_ln_producer": _part(p_ms, p_fl, p_n)},
                          "attention": {"kernel": "attn_kernel", "achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else 0.0,
                                        "launches": a_n, "avg_launch_us": round(a_ms * 1e3 / max(a_n, 1), 2)},
                          "fp8_gemm": ({"kernel": "gemm_bf16_ring<256,256,2,4,2,FP8>", "achieved": round(f_fl / (f_ms * 1e-3) / 1e12, 2), "launches": f_n,

@@ -449,18 +449,25 @@ extern "C" int sg_set_gemm_config(int cfg) {
   return SG_OK;
 }
 extern "C" int sg_profile_disable(void) { g_prof.on = false; return SG_OK; }
-// category: 0 bf16 GEMM (non-persistent tile variants), 1 fused attention, 2 f32 GEMM, 3 the persistent bf16 GEMM, 4 fp8 GEMM.  Call after the stream
+// category: 0 bf16 GEMM (non-persistent tile variants), 1 fused attention, 2 f32 GEMM, 3 the persistent bf16 GEMM (all instantiations), 4 fp8 GEMM,
+// 5 / 6 the persistent GEMM's folded-LayerNorm consumer / producer instantiations alone.  Call after the stream
 // has been synchronised.
 extern "C" int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped) {
   SG_REQUIRE(category >= 0 && category < PROF_NCAT && total_ms && total_flops && launches, "sg_profile_read: bad argument");
-  double ms = 0;
-  for (int i = 0; i < g_prof.used[category]; ++i) {
-    float t = 0.f;
-    SG_HIP(hipEventElapsedTime(&t, g_prof.start[category][i], g_prof.stop[category][i]));
-    ms += t;
+  double ms = 0, work = 0; int64_t n = 0, drop = 0;
+  // category 3 = EVERY launch of the persistent kernel: its plain instantiation plus the two folded-LayerNorm ones (5, 6)
+  const int members[3] = {category, category == PROF_GEMM_PERSIST ? PROF_GEMM_PERSIST_LN_CONSUMER : -1, category == PROF_GEMM_PERSIST ? PROF_GEMM_PERSIST_LN_PRODUCER : -1};
+  for (int c : members) {
+    if (c < 0) continue;
+    for (int i = 0; i < g_prof.used[c]; ++i) {
+      float t = 0.f;
+      SG_HIP(hipEventElapsedTime(&t, g_prof.start[c][i], g_prof.stop[c][i]));
+      ms += t;
+    }
+    work += g_prof.work[c]; n += g_prof.used[c]; drop += g_prof.dropped[c];
   }
-  *total_ms = ms; *total_flops = g_prof.work[category]; *launches = g_prof.used[category];
-  if (dropped) *dropped = g_prof.dropped[category];
+  *total_ms = ms; *total_flops = work; *launches = n;
+  if (dropped) *dropped = drop;
   return SG_OK;
 }
 
@@ -796,8 +803,14 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     // ---- last block: self-self attention on ln_1(x), no residual / MLP when ignore_residual (transformer.py:627-643) ----
     const LayerW& LL = c->layers[L - 1];
     AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1, p.omega, p.qnorm, p.knorm};
-    SG_TRY(layernorm(p.x, D, LL.ln1_g, LL.ln1_b, p.xn, D, c->hk, R, D, 1e-5f, s));
-    SG_TRY(linear(c->hk, p.xn, D, LL.w_qkv, LL.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+    if (x16 && c->hk && !c->fp8 && LL.folded && p.ln_slice && R < (1ll << 31) && gemm_bf16_ln_fold_ok((int)R, D, D) && D % 256 == 0 &&
+        get_gemm_config() != 34) {                                    // block L-2's proj GEMM left x's 2-byte copy and statistics: ln_1 folded here too
+      SG_TRY(ln_stats_finalize(p.ln_slice, R, D, 1e-5f, p.ln_rows, s));
+      SG_TRY(linear_ln_consumer(c->hk, p.xn, D, LL.w_qkv_f, LL.bf_qkv, LL.c_qkv, p.ln_rows, p.qkv, 3 * D, (int)R, 3 * D, D, ACT_NONE, s));
+    } else {
+      SG_TRY(layernorm(p.x, D, LL.ln1_g, LL.ln1_b, p.xn, D, c->hk, R, D, 1e-5f, s));
+      SG_TRY(linear(c->hk, p.xn, D, LL.w_qkv, LL.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
+    }
     if (fusion && o->ignore_residual) {                               // :630-637: the last block's own blk(x) attention joins the EMA
       if (!c->hk) {                                                   // parity mode: materialise the ordinary attention's probabilities
         AttnBuffers av{p.scores, p.probs, p.lse, p.lse1, p.omega, p.qnorm, p.knorm};

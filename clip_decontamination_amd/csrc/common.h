@@ -135,7 +135,8 @@ __device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + e
 enum Act { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
 
 // ---- optional live kernel timing (bench.py roofline): HIP events around the launches of one kernel family ----
-enum ProfCat { PROF_GEMM_BF16 = 0, PROF_ATTENTION = 1, PROF_GEMM_F32 = 2, PROF_GEMM_PERSIST = 3, PROF_GEMM_FP8 = 4, PROF_NCAT = 5 };   // 3: the persistent bf16 kernel alone (the dominant kernel bench.py prices)
+enum ProfCat { PROF_GEMM_BF16 = 0, PROF_ATTENTION = 1, PROF_GEMM_F32 = 2, PROF_GEMM_PERSIST = 3, PROF_GEMM_FP8 = 4, PROF_GEMM_PERSIST_LN_CONSUMER = 5,
+               PROF_GEMM_PERSIST_LN_PRODUCER = 6, PROF_NCAT = 7 };   // 5 / 6: the persistent kernel's folded-LayerNorm instantiations (sg_profile_read(3) includes them)   // 3: the persistent bf16 kernel alone (the dominant kernel bench.py prices)
 bool prof_on();
 void prof_begin(int cat, double work, hipStream_t s);   // work = algorithmic FLOPs of the launch
 void prof_end(int cat, hipStream_t s);

@@ -1491,7 +1491,8 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   if (a.rowdot || ln_fold) cfg = 30;
   if (cfg < 0 || a.f16) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
   if (cfg > 0) {
-    const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? PROF_GEMM_PERSIST : PROF_GEMM_BF16;
+    const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? (a.ln_stats ? PROF_GEMM_PERSIST_LN_CONSUMER : a.copy16 ? PROF_GEMM_PERSIST_LN_PRODUCER : PROF_GEMM_PERSIST)
+                                                         : PROF_GEMM_BF16;
     prof_begin(pcat, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
     int rc;
     switch (cfg) {

@@ -121,11 +121,13 @@ int sg_version(void);
 /* ---- live kernel timing (measurement only; used by bench.py's roofline) -------------------------
  * HIP events bracket every launch of a kernel family on the stream it is launched on.
  * category: 0 = bf16 MFMA GEMM (small-shape tile variants), 1 = fused attention, 2 = f32 MFMA GEMM,
- *           3 = the persistent bf16 GEMM (every large ViT linear; the kernel bench.py's roofline prices), 4 = fp8 GEMM.
+ *           3 = the persistent bf16 GEMM (every large ViT linear; the kernel bench.py's roofline prices: all three instantiations),
+ *           4 = fp8 GEMM, 5 / 6 = the persistent GEMM's folded-LayerNorm consumer / producer instantiations alone (subsets of 3).
  *           Read after synchronising.  The state belongs to the calling thread (enable, launch and read on one thread). */
 int sg_profile_enable(int capacity);
 int sg_profile_disable(void);
-int sg_set_gemm_config(int cfg);   /* tuning hook (calling thread only): bf16 GEMM tile variant, -1 = automatic */
+int sg_set_gemm_config(int cfg);   /* tuning hook (calling thread only): bf16 GEMM tile variant, -1 = automatic; 33 = fp8 MLP without the MXFP8
+                                    * hand-off, 34 = LayerNorm as its own pass (no folding); 1000+ = tile order of the persistent kernel */
 int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped);
 
 /* ---- context and weights ------------------------------------------------------------------
