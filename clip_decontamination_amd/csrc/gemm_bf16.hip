@@ -812,11 +812,15 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 // MODE 1 = the consumer side of a folded LayerNorm (2-byte output only), MODE 2 = the producer side (f32 output + 2-byte copy + slice
 // statistics): their own instantiations, so that the per-row / per-column factors of the one, the statistics of the other and the plain
 // form's deeper residual pipeline never hold registers at the same time.
-template <int MI, int NI, bool F16, int MODE = 0>
-__device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16_rt, int z, int row0,
+template <int MI, int NI, bool F16, int MODE = 0, int SPEC = 0>
+__device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act_rt, int c_bf16_rt, int z, int row0,
                                                 int col0, float* patch, int lane) {
   constexpr bool LN = MODE == 1, PROD = MODE == 2;
-  const int c_bf16 = LN ? 1 : (PROD ? 0 : c_bf16_rt);
+  // SPEC > 0: activation (SPEC - 1), output type (2-byte in MODE 0 / 1, f32 in MODE 2) and the presence of a residual (MODE 2 only) are
+  // compile-time constants -- straight-line strips whose LDS round trips the compiler overlaps (measured on the QKV shape: -3.3 %).
+  // SPEC == 0 keeps every choice at run time (the rarely used combinations and the row-dot form).
+  const int act = SPEC > 0 ? SPEC - 1 : act_rt;
+  const int c_bf16 = (LN || (SPEC > 0 && !PROD)) ? 1 : (PROD ? 0 : c_bf16_rt);
   constexpr int TN = NI * 16, LDP = TN + 4;
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
   float4 bias4[NI];
@@ -859,7 +863,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       } else dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
     }
   };
-  const bool pipe_res = !LN && res != nullptr && !c_bf16;
+  const bool pipe_res = (PROD && SPEC > 0) ? true : (!LN && SPEC == 0 && res != nullptr && !c_bf16);
   if (pipe_res) {
 #pragma unroll
     for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
@@ -897,7 +901,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       // sank the first ds_read_b128 of a strip into the exec-masked write block, so the other half of the wave kept the previous strip's
       // values (found as rows 8-11, 16-19, ... of the producer form carrying the GEMM part of rows 0-3, 8-11, ...).
       int pofs = 0;                                        // an opaque 0 added to every patch read address below: the reads depend on a
-      if constexpr (MODE != 0) asm volatile("" : "+v"(pofs));   // statement that follows the block, so they cannot be moved into it
+      if constexpr (MODE != 0 || SPEC != 0) asm volatile("" : "+v"(pofs));   // statement that follows the block, so they cannot be moved into it
       const int rbase = row0 + i * 16 + hh * 8;
       if (c_bf16) {                                        // 8 lanes x 16 B per row: one instruction stores the whole strip
         constexpr int LPR = TN / 8;
@@ -918,7 +922,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           const int r = r0 + lane / LPR, cq = (lane % LPR) * 4;
           const int m = rbase + r, n = col0 + cq;
           float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq + pofs);
-          if (a.rowdot) {                                    // row-dot epilogue (wave-uniform): v * (2 r + v) summed over this wave's 64 columns
+          if (SPEC == 0 && !PROD && a.rowdot) {              // row-dot epilogue (wave-uniform): v * (2 r + v) summed over this wave's 64 columns
             const float4 rr = rbuf[t % RD][r0 / RPP];
             float d = x.x * (2.f * rr.x + x.x) + x.y * (2.f * rr.y + x.y) + x.z * (2.f * rr.z + x.z) + x.w * (2.f * rr.w + x.w);
 #pragma unroll
@@ -963,7 +967,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
 
 // EPI: 0 = the plain epilogue, 1 / 2 = the consumer / producer side of a folded LayerNorm (epilogue_store8's MODE): separate kernels, so
 // that the plain one keeps exactly the register allocation it was tuned with.
-template <bool F16, int EPI = 0>
+template <bool F16, int EPI = 0, int SPEC = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act, int c_bf16) {
   constexpr int PBM = 256, PBN = 256, KT32 = 32;
   constexpr int TILE_B = (PBM + PBN) * KT32 * 2;             // 32 KiB per ring slot
@@ -1094,7 +1098,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
     if (g == 0) SG_PS_SYNC();                               // align: every read of this tile's last K tile has retired
     {
       float* patch = reinterpret_cast<float*>(lds + ((s - 1) & 3) * TILE_B) + wave * 576;   // 8 rows x 68 floats (+pad) per wave
-      epilogue_store8<8, 4, F16, EPI>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
+      epilogue_store8<8, 4, F16, EPI, SPEC>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);
@@ -1377,9 +1381,21 @@ static int launch_fp8_persist(const GemmBf16Args& a, hipStream_t s) {
 
 static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
-  auto kern = a.ln_stats ? (a.f16 ? gemm_bf16_persist<true, 1> : gemm_bf16_persist<false, 1>)
-            : a.copy16 ? (a.f16 ? gemm_bf16_persist<true, 2> : gemm_bf16_persist<false, 2>)
-                       : (a.f16 ? gemm_bf16_persist<true, 0> : gemm_bf16_persist<false, 0>);
+  // instantiation: epilogue form (plain / folded-LayerNorm consumer / producer) x compile-time specialisation of the hot combinations
+  using Kern = void (*)(GemmBf16Args, int, int);
+  Kern kern;
+  if (a.ln_stats) {                                         // consumer: 2-byte output, activation per layer kind
+    kern = a.act == ACT_NONE ? (a.f16 ? gemm_bf16_persist<true, 1, 1> : gemm_bf16_persist<false, 1, 1>)
+         : a.act == ACT_QUICK_GELU ? (a.f16 ? gemm_bf16_persist<true, 1, 2> : gemm_bf16_persist<false, 1, 2>)
+                                   : (a.f16 ? gemm_bf16_persist<true, 1, 3> : gemm_bf16_persist<false, 1, 3>);
+  } else if (a.copy16) {                                    // producer: f32 output + residual, no activation
+    SG_REQUIRE(a.residual && a.act == ACT_NONE, "gemm_bf16: the folded-LayerNorm producer form is a residual GEMM without activation");
+    kern = a.f16 ? gemm_bf16_persist<true, 2, 1> : gemm_bf16_persist<false, 2, 1>;
+  } else if (a.c_is_bf16 && !a.residual && !a.rowdot && a.act == ACT_NONE) {
+    kern = a.f16 ? gemm_bf16_persist<true, 0, 1> : gemm_bf16_persist<false, 0, 1>;
+  } else {
+    kern = a.f16 ? gemm_bf16_persist<true, 0, 0> : gemm_bf16_persist<false, 0, 0>;
+  }
   SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int n_cu = device_cu_count();
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
