@@ -149,11 +149,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
 // tile goes through a private LDS patch (row stride TN+4 floats: conflict-free 16-byte writes) and comes back row-contiguous, so a
 // store instruction writes WHOLE 128-byte lines (8 rows x 128 B bf16, 4 rows x 256 B f32); bias / activation are applied before
 // the patch, the f32 residual is added on the way out with equally coalesced loads.
-template <int MI, int NI, bool F16 = false>
-__device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act, int c_bf16, int z, int row0,
+// SPEC > 0 fixes the hot combinations of the fp8 linears at compile time (as gemm_bf16_persist's epilogue does): 1 = 2-byte output, no
+// activation (QKV); 2 / 3 = MXFP8 output after QuickGELU / GELU (fc); 4 = f32 output + f32 residual, no activation (proj).
+template <int MI, int NI, bool F16 = false, int SPEC = 0>
+__device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act_rt, int c_bf16_rt, int z, int row0,
                                                int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
-  const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
+  const int act = SPEC == 0 ? act_rt : (SPEC == 2 ? (int)ACT_QUICK_GELU : SPEC == 3 ? (int)ACT_GELU : (int)ACT_NONE);
+  const int c_bf16 = SPEC == 0 ? c_bf16_rt : (SPEC != 4);
+  const bool mx_out = SPEC == 0 ? a.c_mx != nullptr : (SPEC == 2 || SPEC == 3);
+  const float* res = (SPEC == 0 || SPEC == 4) ? (a.residual ? a.residual + (int64_t)z * a.strideC : nullptr) : nullptr;
   float4 bias4[NI], cs4[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -188,7 +193,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
       for (int r0 = 0; r0 < 16; r0 += RPP) {
         const int r = r0 + lane / LPR, cq = (lane % LPR) * 8;
         const int m = rbase + r, n = col0 + cq;
-        if (a.c_mx) {                                       // MXFP8 output: e4m3 + one E8M0 scale per 32 columns (4 adjacent lanes of a row)
+        if (mx_out) {                                       // MXFP8 output: e4m3 + one E8M0 scale per 32 columns (4 adjacent lanes of a row)
           static_assert(TN % 32 == 0, "MX blocks are 32 columns");
           const bool ok = r < 16 && m < a.M && n < a.N;
           const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
@@ -225,7 +230,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
         const int m = rbase + r, n = col0 + cq;
         if (r < 16 && m < a.M && n < a.N) {
           float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
-          if (res) {
+          if (SPEC == 4 || res) {
             const float4 rr = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
             x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
           }
@@ -256,7 +261,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // The legacy v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate on gfx950 (tools/mfma_rate.hip: 2.1 vs 4.8 PFLOP/s), so it is not used.
 // MXA (fp8 only): A carries MX block scales (GemmBf16Args::a_mx): every K tile stages one more piece -- the dwords holding the four E8M0
 // scales of each A row -- behind the operand image, and the MFMA's second scale operand gets the lane's own byte.
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false, int SPEC = 0>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MI = TM / 16, NI = TN / 16;
   constexpr int RPS = BKT == 64 ? 8 : 16;                // rows per 1 KiB slab (row = BKT * 2 bytes)
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
   }
   if (vec) {                                               // N % 8 == 0, aligned: coalesced path through an LDS patch
     __syncthreads();                                       // every wave is done reading the staging buffers
-    epilogue_store<MI, NI, F16>(acc, a, act, c_bf16, z, m0 + wave_m * TM, n0 + wave_n * TN, reinterpret_cast<float*>(lds) + wave * 16 * (TN + 4), lane);
+    epilogue_store<MI, NI, F16, SPEC>(acc, a, act, c_bf16, z, m0 + wave_m * TM, n0 + wave_n * TN, reinterpret_cast<float*>(lds) + wave * 16 * (TN + 4), lane);
     return;
   }
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
@@ -819,8 +824,10 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
   // SPEC > 0: activation (SPEC - 1), output type (2-byte in MODE 0 / 1, f32 in MODE 2) and the presence of a residual (MODE 2 only) are
   // compile-time constants -- straight-line strips whose LDS round trips the compiler overlaps (measured on the QKV shape: -3.3 %).
   // SPEC == 0 keeps every choice at run time (the rarely used combinations and the row-dot form).
-  const int act = SPEC > 0 ? SPEC - 1 : act_rt;
-  const int c_bf16 = (LN || (SPEC > 0 && !PROD)) ? 1 : (PROD ? 0 : c_bf16_rt);
+  // SPEC == 4 (MODE 0 only): f32 output + f32 residual, no activation -- the plain residual GEMM (fp8 mode's out-proj, the last block, the text tower).
+  constexpr bool RES32 = MODE == 0 && SPEC == 4;
+  const int act = SPEC > 0 ? (RES32 ? (int)ACT_NONE : SPEC - 1) : act_rt;
+  const int c_bf16 = (LN || (SPEC > 0 && !PROD && !RES32)) ? 1 : ((PROD || RES32) ? 0 : c_bf16_rt);
   constexpr int TN = NI * 16, LDP = TN + 4;
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
   float4 bias4[NI];
@@ -856,14 +863,14 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
     for (int ps = 0; ps < NPASS; ++ps) {
       int m = rb + ps * RPPF + lane / LPRF; m = m < a.M ? m : a.M - 1;
       int n = col0 + (lane % LPRF) * 4; n = n < a.N ? n : a.N - 4;
-      if (a.rowdot && a.rowdot_res_bf16) {               // the JBU tail keeps x in bf16 only (wave-uniform branch)
+      if (SPEC == 0 && a.rowdot && a.rowdot_res_bf16) {   // the JBU tail keeps x in bf16 only (wave-uniform branch)
         const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(res) + (int64_t)m * a.ldr + n);
         dst[ps] = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
                               __uint_as_float(raw.y & 0xffff0000u));
       } else dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
     }
   };
-  const bool pipe_res = (PROD && SPEC > 0) ? true : (!LN && SPEC == 0 && res != nullptr && !c_bf16);
+  const bool pipe_res = ((PROD && SPEC > 0) || RES32) ? true : (!LN && SPEC == 0 && res != nullptr && !c_bf16);
   if (pipe_res) {
 #pragma unroll
     for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
@@ -1393,6 +1400,8 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
     kern = a.f16 ? gemm_bf16_persist<true, 2, 1> : gemm_bf16_persist<false, 2, 1>;
   } else if (a.c_is_bf16 && !a.residual && !a.rowdot && a.act == ACT_NONE) {
     kern = a.f16 ? gemm_bf16_persist<true, 0, 1> : gemm_bf16_persist<false, 0, 1>;
+  } else if (!a.c_is_bf16 && a.residual && !a.rowdot && a.act == ACT_NONE) {
+    kern = a.f16 ? gemm_bf16_persist<true, 0, 4> : gemm_bf16_persist<false, 0, 4>;
   } else {
     kern = a.f16 ? gemm_bf16_persist<true, 0, 0> : gemm_bf16_persist<false, 0, 0>;
   }
@@ -1426,9 +1435,9 @@ void set_gemm_config(int c) {
 }
 
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false, int SPEC = 0>
 static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
-  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8, F16, MXA>;
+  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8, F16, MXA, SPEC>;
   const size_t lds = (size_t)STAGES * ((BM_ + BN_) * BKT * 2 + (MXA ? BM_ * 4 : 0));
   if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
@@ -1463,7 +1472,14 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   const bool mx = a.a_mx != nullptr || a.c_mx != nullptr;
   if (mx) {                                               // MX operands / MX output live in the ring kernel (the persistent kernel's LDS is full)
     SG_REQUIRE(vec && a.batch == 1 && a.M >= 1024 && a.N >= 256, "gemm_fp8: the MX forms need the large-shape vector path");
-    const int rcm = a.a_mx ? launch_ring<256, 256, 2, 4, 2, 0, 64, true, false, true>(h, vec, s) : launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s);
+    // the tower's MLP hand-off runs on compile-time-specialised epilogues: fc -> MX output after the activation, proj <- MX operand, f32 + residual
+    const bool proj_form = a.a_mx && !a.c_mx && !a.c_is_bf16 && a.residual && a.act == ACT_NONE;
+    const bool fc_form = !a.a_mx && a.c_mx && (a.act == ACT_QUICK_GELU || a.act == ACT_GELU);
+    const int rcm = proj_form ? launch_ring<256, 256, 2, 4, 2, 0, 64, true, false, true, 4>(h, vec, s)
+                  : a.a_mx ? launch_ring<256, 256, 2, 4, 2, 0, 64, true, false, true>(h, vec, s)
+                  : fc_form ? (a.act == ACT_QUICK_GELU ? launch_ring<256, 256, 2, 4, 2, 0, 64, true, false, false, 2>(h, vec, s)
+                                                       : launch_ring<256, 256, 2, 4, 2, 0, 64, true, false, false, 3>(h, vec, s))
+                            : launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s);
     prof_end(PROF_GEMM_FP8, s);
     if (rcm != SG_OK) return rcm;
     SG_LAUNCH_CHECK();
@@ -1472,7 +1488,8 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   const bool persist = vec && a.batch == 1 && a.M >= 1024 && a.N >= 512 && (a.K >= 2048 || g_gemm_config == 32) && a.K >= 512 && g_gemm_config != 31 &&
                        (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);     // 32-bit byte offsets inside the kernel
   const int rc = persist ? launch_fp8_persist(a, s)
-               : (a.M >= 1024 && a.N >= 256) ? launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s)
+               : (a.M >= 1024 && a.N >= 256) ? ((vec && a.c_is_bf16 && !a.residual && a.act == ACT_NONE) ? launch_ring<256, 256, 2, 4, 2, 0, 64, true, false, false, 1>(h, vec, s)
+                                                                                                      : launch_ring<256, 256, 2, 4, 2, 0, 64, true>(h, vec, s))
                                              : launch_ring<128, 128, 2, 2, 3, 0, 64, true>(h, vec, s);
   prof_end(PROF_GEMM_FP8, s);
   if (rc != SG_OK) return rc;
