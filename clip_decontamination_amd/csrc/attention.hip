@@ -87,7 +87,7 @@ __device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u
 // MULTI = several separately soft-maxed streams are summed (SCLIP / SegEarth / GEM); otherwise no second accumulator.
 // Lean variants are capped at 256 registers (VGPR-form MFMA, 2+ waves per SIMD); the register-hungry ones (bias + multi-stream,
 // head_dim > 64) may take the whole file rather than spill.
-template <int DH, int TS, bool GENERIC, bool MULTI, bool F16>
+template <int DH, int TS, bool GENERIC, bool MULTI, bool F16, bool PV>
 __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC || MULTI || DH > 80))) ? 1 : 2) void attn_kernel(AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
   const int n = a.N - 1;
   const float scale = a.scale_per_image ? a.scale_per_image[b] : a.scale;      // > 0
   const float c2 = scale * LOG2E;                                              // scores live in the exp2 domain
-  const bool do_pv = a.ctx != nullptr;
+  constexpr bool do_pv = PV;                                                   // a context is wanted (false: the log-sum-exp pass alone) -- a template
+                                                                               // parameter, so that the key-tile loop is free of run-time branches
   const int n_streams = MULTI ? a.n_terms : 1;
   const int64_t head_off = (int64_t)b * a.sb + (int64_t)hd * DH;
   const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + (int64_t)hd * DH;
@@ -400,8 +401,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   // TS == 2 means two SUMMED score terms = one stream: the multi-stream variants exist for TS == 1 only
   constexpr bool CAN_MULTI = TS == 1;
   SG_REQUIRE(CAN_MULTI || !multi, "attention: summed terms and separate streams are exclusive");
-  auto kern = generic ? (multi ? attn_kernel<DH, TS, true, CAN_MULTI, AF16> : attn_kernel<DH, TS, true, false, AF16>)
-                      : (multi ? attn_kernel<DH, TS, false, CAN_MULTI, AF16> : attn_kernel<DH, TS, false, false, AF16>);
+  using Kern = void (*)(AttnArgs);
+  const Kern kern = a.ctx ? (generic ? (multi ? attn_kernel<DH, TS, true, CAN_MULTI, AF16, true> : attn_kernel<DH, TS, true, false, AF16, true>)
+                                     : (multi ? attn_kernel<DH, TS, false, CAN_MULTI, AF16, true> : attn_kernel<DH, TS, false, false, AF16, true>))
+                          : (generic ? attn_kernel<DH, TS, true, false, AF16, false> : attn_kernel<DH, TS, false, false, AF16, false>);
+  SG_REQUIRE(a.ctx || !multi, "attention: a log-sum-exp-only pass has one stream");
   if (lds > 64 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t nqb = cdiv(a.N, QB);
   const int64_t nblk = (generic && a.bias) ? cdiv((int64_t)a.B * nqb, 8) * 8 * a.H : cdiv((int64_t)a.H * a.B, 8) * 8 * nqb;
