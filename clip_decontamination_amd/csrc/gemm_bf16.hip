@@ -812,8 +812,6 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 //        A(s+2), W(s+2), A(s+3) = 6), group 1 after READ(s) (tiles s+2, s+3 = 8); both before the barrier closing slot 2s+1.
 //   tile end: group 0 takes one extra barrier (both groups are then past every read of the tile's last K tile), every wave runs the
 //        coalescing epilogue through a private patch inside the just-consumed ring slot, one barrier, group 1 re-staggers.
-// LN = the consumer side of a folded LayerNorm (2-byte output only): its own instantiation, so that its per-row / per-column factors and
-// the other form's residual pipeline do not hold registers at the same time.
 // MODE 1 = the consumer side of a folded LayerNorm (2-byte output only), MODE 2 = the producer side (f32 output + 2-byte copy + slice
 // statistics): their own instantiations, so that the per-row / per-column factors of the one, the statistics of the other and the plain
 // form's deeper residual pipeline never hold registers at the same time.
@@ -822,7 +820,8 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
                                                 int col0, float* patch, int lane) {
   constexpr bool LN = MODE == 1, PROD = MODE == 2;
   // SPEC > 0: activation (SPEC - 1), output type (2-byte in MODE 0 / 1, f32 in MODE 2) and the presence of a residual (MODE 2 only) are
-  // compile-time constants -- straight-line strips whose LDS round trips the compiler overlaps (measured on the QKV shape: -3.3 %).
+  // compile-time constants -- straight-line strips without the run-time branches (measured on the QKV shape: -3.3 %; overlapping the
+  // strips' LDS round trips on top of that brought nothing: the epilogue is bound by store issue).
   // SPEC == 0 keeps every choice at run time (the rarely used combinations and the row-dot form).
   // SPEC == 4 (MODE 0 only): f32 output + f32 residual, no activation -- the plain residual GEMM (fp8 mode's out-proj, the last block, the text tower).
   constexpr bool RES32 = MODE == 0 && SPEC == 4;
