@@ -264,3 +264,29 @@ def test_known_answer_centre_of_a_3x3_grid():
     assert torch.allclose(out[0, :, 1, 1], torch.full((4,), 5.0), atol=1e-6)
     weak = OR.replace_weak_tokens(grid, torch.tensor([[4]]))
     assert torch.allclose(weak[0, :, 1, 1], torch.full((4,), 5.0), atol=1e-6)
+
+
+def test_layernorm_folding_identity_and_slice_statistics():
+    """The algebra the 2-byte modes rely on (csrc/rowops.hip): LayerNorm(x; gamma, beta) @ W^T + b equals
+    rstd * (x @ W'^T - mean * c) + b' with W' = gamma o W, c = row sums of W', b' = b + W @ beta; and per-64-column (sum, centred sum
+    of squares) slices combine (Chan) to the row's mean and variance, whatever the mean is."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    M, D, N = 37, 256, 48
+    x = rng.standard_normal((M, D)) * np.logspace(-1, 1, M)[:, None] + rng.standard_normal((M, 1)) * 3.0
+    g, be = 1 + 0.3 * rng.standard_normal(D), 0.2 * rng.standard_normal(D)
+    W, b = rng.standard_normal((N, D)) / 16, rng.standard_normal(N)
+    mu, var = x.mean(1, keepdims=True), x.var(1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + 1e-5)
+    want = ((x - mu) * rstd * g + be) @ W.T + b
+    Wf = W * g
+    got = rstd * (x @ Wf.T - mu * Wf.sum(1)) + (b + W @ be)
+    assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+    # slice statistics -> (mean, variance)
+    sl = x.reshape(M, D // 64, 64)
+    s = sl.sum(2)
+    q = ((sl - s[..., None] / 64) ** 2).sum(2)
+    mean = s.sum(1) / D
+    m2 = (q + 64 * (s / 64 - mean[:, None]) ** 2).sum(1)
+    assert np.abs(mean - mu[:, 0]).max() < 1e-12 * (1 + np.abs(mu).max())
+    assert np.abs(m2 / D - var[:, 0]).max() < 1e-10 * var.max()
