@@ -250,11 +250,17 @@ def main():
         tl = last["tl"]
         picks = sorted({0, len(my_local) // 2, len(my_local) - 1})
         worst, exact = 0.0, True
-        for i in picks:
-            alone = pipe.tile_logits(slab, [my_local[i]], (TILE, TILE))[0]
-            d = (alone - tl[i]).abs().max().item()
-            worst = max(worst, d)
-            exact = exact and bool(torch.equal(alone, tl[i]))
+        # a one-tile launch would normally take the small-launch dispatch (128 x 128 GEMM tiles, LayerNorm as its own pass); tuning code 36
+        # keeps it on the kernels of the timed launch, so that what is compared is the 128-tile stream against a single tile of the SAME code
+        lib.sg_set_gemm_config(36)
+        try:
+            for i in picks:
+                alone = pipe.tile_logits(slab, [my_local[i]], (TILE, TILE))[0]
+                d = (alone - tl[i]).abs().max().item()
+                worst = max(worst, d)
+                exact = exact and bool(torch.equal(alone, tl[i]))
+        finally:
+            lib.sg_set_gemm_config(-1 if args.tuning is None else int(args.tuning))
         if not (worst < 1e-3):
             raise SystemExit(f"bench self-check FAILED: a tile of the {len(my_local)}-tile launch differs from the same tile run alone by {worst}")
         return {"tiles_checked": len(picks), "max_dlogit_batched_vs_alone": worst, "bit_identical": exact}

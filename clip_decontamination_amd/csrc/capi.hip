@@ -688,8 +688,9 @@ static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
   const int64_t R = (int64_t)B * N;
   AttnBuffers ab{p.scores, p.probs, p.lse, p.lse1, p.omega, p.qnorm, p.knorm};
   // LayerNorm folding: 2-byte modes, shapes that run on the persistent GEMM; cfg 34 (tuning) switches it off
+  // (small launches -- a tile or two per call -- run the residual GEMMs on smaller tiles instead, see gemm_bf16.hip few_tiles)
   const bool fold = c->hk && !c->fp8 && L.folded && p.ln_slice && R < (1ll << 31) && gemm_bf16_ln_fold_ok((int)R, D, D) && D % 256 == 0 &&
-                    get_gemm_config() != 34;
+                    gemm_bf16_prefers_persistent((int)R, D) && get_gemm_config() != 34;
   const bool ln1_folded = fold && x16_valid && *x16_valid;
   if (x16_valid) *x16_valid = false;
   if (c->fp8 && p.x8 && L.w_qkv8) {
@@ -804,7 +805,7 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
     const LayerW& LL = c->layers[L - 1];
     AttnBuffers ab{p.scores, p.probs, p.lse1, p.lse1, p.omega, p.qnorm, p.knorm};
     if (x16 && c->hk && !c->fp8 && LL.folded && p.ln_slice && R < (1ll << 31) && gemm_bf16_ln_fold_ok((int)R, D, D) && D % 256 == 0 &&
-        get_gemm_config() != 34) {                                    // block L-2's proj GEMM left x's 2-byte copy and statistics: ln_1 folded here too
+        gemm_bf16_prefers_persistent((int)R, D) && get_gemm_config() != 34) {                                    // block L-2's proj GEMM left x's 2-byte copy and statistics: ln_1 folded here too
       SG_TRY(ln_stats_finalize(p.ln_slice, R, D, 1e-5f, p.ln_rows, s));
       SG_TRY(linear_ln_consumer(c->hk, p.xn, D, LL.w_qkv_f, LL.bf_qkv, LL.c_qkv, p.ln_rows, p.qkv, 3 * D, (int)R, 3 * D, D, ACT_NONE, s));
     } else {

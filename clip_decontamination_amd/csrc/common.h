@@ -180,7 +180,8 @@ struct GemmBf16Args {
 };
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s);
 int get_gemm_config();
-bool gemm_bf16_ln_fold_ok(int M, int N, int K);   // the shapes whose dispatch reaches the persistent kernel (the folded-LayerNorm epilogues live there)
+bool gemm_bf16_ln_fold_ok(int M, int N, int K);   // the shapes the persistent kernel (home of the folded-LayerNorm epilogues) can run
+bool gemm_bf16_prefers_persistent(int M, int N);  // ... and whether the automatic dispatch would pick it (enough 256 x 256 tiles to fill the chip)
 void set_gemm_config(int c);   // tuning hook (per calling thread): -1 auto, 0 = 128x128x2-stage baseline, 1.. = ring variants
 
 // f32 GEMM (f32 MFMA, exact fmaf chains), fully general strides: A(m,k) at A[m*lda + k];

@@ -1427,7 +1427,13 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
 
 static thread_local int g_gemm_config = -1;                // -1 = pick per shape (tuning override, per calling thread)
 int get_gemm_config() { return g_gemm_config; }
+// A launch whose 256 x 256 tiles would not even fill half the CUs (one or two image tiles per call: the reference's own tile-by-tile loop)
+// runs on the 128 x 128 ring kernel instead -- four times the workgroups, measured 1.4-2x faster there; tuning code 36 switches this off.
+static bool few_tiles(int M, int N) {
+  return g_gemm_config != 36 && (int64_t)cdiv(M, 256) * cdiv(N, 256) * 2 < device_cu_count();
+}
 bool gemm_bf16_ln_fold_ok(int M, int N, int K) { return M >= 1024 && N >= 512 && N % 64 == 0 && K % 32 == 0 && K / 32 >= 4; }
+bool gemm_bf16_prefers_persistent(int M, int N) { return M >= 1024 && N >= 512 && !few_tiles(M, N); }
 void set_gemm_config(int c) {
   if (c >= 1000) { g_gemm_order = c - 1001; return; }      // 1000 -> -1 (automatic), 1001 -> 0 (raster), 1001 + v -> N-group size v
   g_gemm_config = c;
@@ -1519,9 +1525,9 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
     if (a.ln_stats) SG_REQUIRE(a.ln_c && a.alpha == 1.f && a.c_is_bf16 && !a.residual && !a.rowdot && ((((uintptr_t)a.ln_c) & 15) == 0) && ((((uintptr_t)a.ln_stats) & 7) == 0), "gemm_bf16: ln_stats needs ln_c and alpha 1");
   }
   int cfg = g_gemm_config;
-  if (cfg == 33 || cfg == 34) cfg = -1;                    // tuning codes read by capi.hip (MX hand-off / LayerNorm folding off), not tile configurations
+  if (cfg == 33 || cfg == 34 || cfg == 36) cfg = -1;                    // tuning codes read by capi.hip (MX hand-off / LayerNorm folding off), not tile configurations
   if (a.rowdot || ln_fold) cfg = 30;
-  if (cfg < 0 || a.f16) cfg = (a.M >= 1024 && a.N >= 512) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
+  if (cfg < 0 || a.f16) cfg = (a.rowdot || ln_fold || (a.M >= 1024 && a.N >= 512 && !(few_tiles(a.M, a.N) && a.batch == 1))) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
   if (cfg > 0) {
     const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? (a.ln_stats ? PROF_GEMM_PERSIST_LN_CONSUMER : a.copy16 ? PROF_GEMM_PERSIST_LN_PRODUCER : PROF_GEMM_PERSIST)
                                                          : PROF_GEMM_BF16;

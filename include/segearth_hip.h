@@ -127,7 +127,8 @@ int sg_version(void);
 int sg_profile_enable(int capacity);
 int sg_profile_disable(void);
 int sg_set_gemm_config(int cfg);   /* tuning hook (calling thread only): bf16 GEMM tile variant, -1 = automatic; 33 = fp8 MLP without the MXFP8
-                                    * hand-off, 34 = LayerNorm as its own pass (no folding); 1000+ = tile order of the persistent kernel */
+                                    * hand-off, 34 = LayerNorm as its own pass (no folding), 36 = no small-launch dispatch (a few-tile GEMM stays on the
+                                    * persistent kernel); 1000+ = tile order of the persistent kernel */
 int sg_profile_read(int category, double* total_ms, double* total_flops, int64_t* launches, int64_t* dropped);
 
 /* ---- context and weights ------------------------------------------------------------------

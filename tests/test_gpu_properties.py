@@ -30,8 +30,10 @@ def test_tile_result_does_not_depend_on_its_batch_or_position(pipe):
     wins = [(y, y + 512, x, x + 512) for y in (0, 256, 1024) for x in (0, 512, 768, 1024)]
     all12 = pipe.tile_logits(scene, wins, (512, 512))
     alone = pipe.tile_logits(scene, [wins[5]], (512, 512))
-    # different launch sizes may pick different GEMM tilings (summation order): bf16-level agreement, same arg-max almost everywhere
-    assert (all12[5] - alone[0]).abs().max().item() < 2e-3
+    # different launch sizes pick different GEMM kernels (12 tiles: persistent 256 x 256 tiles with the LayerNorms folded in; one tile: the
+    # small-launch dispatch, 128 x 128 tiles and LayerNorm passes): two bf16 roundings of the same numbers -- measured 2.1e-3, the distance
+    # of either from the fp32 oracle is 4.7e-3 -- and the same arg-max almost everywhere
+    assert (all12[5] - alone[0]).abs().max().item() < 4e-3
     assert (all12[5].argmax(0) == alone[0].argmax(0)).float().mean().item() > 0.995
     # the same pixels copied to another place of the scene, same launch shape: bit-identical
     y, x = wins[5][0], wins[5][2]
@@ -52,12 +54,15 @@ def test_bench_launch_shape_128_tiles_equals_single_tile_launches(pipe):
     scene = torch.from_numpy(np.ascontiguousarray(Wt.make_tiles_u8(1, W, seed=1234, smooth=True)[0][:H, :W])).to(DEV)
     wins = tile_windows(H, W, (256, 256), (512, 512))
     assert len(wins) == 128
+    from clip_decontamination_amd import _lib
+    lib = _lib.load()
     old = pipe.tiles_per_launch
     try:
         pipe.tiles_per_launch = 128
         batched = pipe.tile_logits(scene, wins, (512, 512))
         assert batched.shape == (128, len(QIDX), 37, 37) and torch.isfinite(batched).all()
         worst = 0.0
+        lib.sg_set_gemm_config(36)                                 # one-tile launches on the big launch's kernels (not the small-launch dispatch)
         for i in (0, 37, 64, 101, 127):
             alone = pipe.tile_logits(scene, [wins[i]], (512, 512))[0]
             d = (batched[i] - alone).abs().max().item()
@@ -65,9 +70,15 @@ def test_bench_launch_shape_128_tiles_equals_single_tile_launches(pipe):
             assert d < 1e-5, (i, d)                                # measured (r2): bit-identical (same kernels, same K order per element)
             assert torch.equal(batched[i].argmax(0), alone.argmax(0)), i
         print(f"128-tile launch vs single-tile launches: max|dlogit| = {worst:.3e}")
+        lib.sg_set_gemm_config(-1)
         again = pipe.tile_logits(scene, wins, (512, 512))
         assert torch.equal(again, batched)                         # deterministic at the bench launch shape
+        # and with the small-launch dispatch a lone tile still agrees to 2-byte rounding
+        alone = pipe.tile_logits(scene, [wins[64]], (512, 512))[0]
+        assert (batched[64] - alone).abs().max().item() < 2e-3
+        assert (batched[64].argmax(0) == alone.argmax(0)).float().mean().item() > 0.995
     finally:
+        lib.sg_set_gemm_config(-1)
         pipe.tiles_per_launch = old
 
 
@@ -128,9 +139,9 @@ def test_two_contexts_on_two_host_threads():
     cfg = Wt.vit_config("ViT-B-16")
     w = Wt.make_vit_weights(cfg, seed=0)
     towers = [HipVisionTower(cfg, w, precision="bf16", device=DEV) for _ in range(2)]
-    tiles = torch.from_numpy(Wt.make_tiles_u8(8, 224, seed=21, smooth=True)).to(DEV)            # R = 8 * 197 rows: the persistent GEMM path
-    win = torch.tensor([[0, 224, 0, 224]] * 8, dtype=torch.int32)
-    idx = torch.arange(8, dtype=torch.int32)
+    tiles = torch.from_numpy(Wt.make_tiles_u8(64, 224, seed=21, smooth=True)).to(DEV)           # R = 64 * 197 rows: enough tiles for the persistent GEMM path
+    win = torch.tensor([[0, 224, 0, 224]] * 64, dtype=torch.int32)
+    idx = torch.arange(64, dtype=torch.int32)
     want = []
     for t in towers:
         c, tok = t.forward_tiles(tiles, win, (224, 224), t.forward_opts("SegEarth", True), idx)
