@@ -174,6 +174,22 @@ def sharded_cross_tile_fusion(tokens: torch.Tensor, steps, n_tiles: int, world: 
     return steps.apply(tokens, lo, left_res, top_res)
 
 
+def launch_chunks(n_tiles: int, limit: int) -> List[Tuple[int, int]]:
+    """[start, stop) ranges of the tile list, one per launch of the tower: as few launches as `limit` tiles per launch allows, of EQUAL size
+    (33 tiles at a limit of 32 run as 17 + 16, not 32 + 1 -- a one- or two-tile launch leaves most of the chip idle)."""
+    if n_tiles <= 0:
+        return []
+    limit = max(1, int(limit))
+    n = -(-n_tiles // limit)
+    base, extra = divmod(n_tiles, n)
+    out, a = [], 0
+    for i in range(n):
+        b = a + base + (1 if i < extra else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
 class SegPipeline:
     def __init__(self, net: HipCLIP, text: torch.Tensor, query_idx: torch.Tensor, model_type: str = "SegEarth",
                  ignore_residual: bool = True, cls_token_lambda: float = 0.0, global_debias_factor: float = 0.0,
@@ -234,9 +250,9 @@ class SegPipeline:
         if fuse:
             # boundary fusion couples neighbouring tiles: run the tower over the whole scene first, fuse, then the head
             cls_all, tok_all = [], []
-            for i in range(0, win.shape[0], self.tiles_per_launch):
-                si = None if scene_index is None else scene_index[i:i + self.tiles_per_launch]
-                c_, t_ = v.forward_tiles(scene, win[i:i + self.tiles_per_launch], tile_hw, opts, si)
+            for i, j in launch_chunks(win.shape[0], self.tiles_per_launch):
+                si = None if scene_index is None else scene_index[i:j]
+                c_, t_ = v.forward_tiles(scene, win[i:j], tile_hw, opts, si)
                 cls_all.append(c_); tok_all.append(t_)
             tok = ops.cross_tile_fusion(torch.cat(tok_all, 0), grid_of_tiles[0], grid_of_tiles[1], gh, gw,
                                         self.cross_tile_fusion.get("cache_boundary_width", 2),
@@ -248,9 +264,9 @@ class SegPipeline:
             tok, f = self._pre_head(tok, cls)
             lg = ops.cosine_logits(tok, cls, self.text, f, self.cls_token_lambda if cls is not None else 0.0)
             return lg.reshape(win.shape[0], self.num_queries, gh, gw)
-        for i in range(0, win.shape[0], self.tiles_per_launch):
-            w = win[i:i + self.tiles_per_launch]
-            si = None if scene_index is None else scene_index[i:i + self.tiles_per_launch]
+        for i, j in launch_chunks(win.shape[0], self.tiles_per_launch):
+            w = win[i:j]
+            si = None if scene_index is None else scene_index[i:j]
             cls, tok = v.forward_tiles(scene, w, tile_hw, opts, si)
             tok, f = self._pre_head(tok, cls)
             if self.upsampler is not None:
@@ -380,8 +396,8 @@ class SegPipeline:
                               getattr(self, "apply_layer_fusion", False), getattr(self, "layer_fusion_lambda", 0.5))
         win = torch.tensor(list(mine), dtype=torch.int32, device=self.device).reshape(-1, 4)
         cls_all, tok_all = [], []
-        for i in range(0, win.shape[0], self.tiles_per_launch):
-            c_, t_ = v.forward_tiles(scene, win[i:i + self.tiles_per_launch], tile_hw, opts, None)
+        for i, j in launch_chunks(win.shape[0], self.tiles_per_launch):
+            c_, t_ = v.forward_tiles(scene, win[i:j], tile_hw, opts, None)
             cls_all.append(c_); tok_all.append(t_)
         tok = torch.cat(tok_all, 0)[:n_real].contiguous()
         cls = None if cls_all[0] is None else torch.cat(cls_all, 0)[:n_real].contiguous()

@@ -306,3 +306,17 @@ def test_band_plan_covers_canvas_and_needs_only_lower_ranks():
                     assert a <= lo and b == hi
                     covering = [t for t, w in enumerate(wins) if w[1] > yb[r] and w[0] < yb[r + 1]]
                     assert covering and covering[0] >= a and covering[-1] < b, (H, world, r)
+
+
+def test_launch_chunks_are_balanced_and_cover_the_tile_list():
+    from clip_decontamination_amd.pipeline import launch_chunks
+    assert launch_chunks(0, 32) == []
+    assert launch_chunks(33, 32) == [(0, 17), (17, 33)]
+    assert launch_chunks(32, 32) == [(0, 32)]
+    assert launch_chunks(5, 1) == [(i, i + 1) for i in range(5)]
+    for n in range(1, 200):
+        for lim in (1, 7, 32, 128):
+            ch = launch_chunks(n, lim)
+            assert ch[0][0] == 0 and ch[-1][1] == n and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+            sizes = [b - a for a, b in ch]
+            assert max(sizes) <= lim and max(sizes) - min(sizes) <= 1 and len(ch) == -(-n // lim)
