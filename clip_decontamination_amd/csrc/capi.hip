@@ -621,12 +621,11 @@ extern "C" int sg_vit_finalize(sg_context* c, sg_stream st) {
   // parameters were replaced without its weights keeps the explicit LayerNorm pass (folded == false)
   DeviceGuard dg(c->device);
   const int D = c->d.width, M = c->d.mlp_width;
-  bool any = false;
   for (auto& L : c->layers) {
     if (!L.w_qkv_f || L.folded || !L.stage_qkv || !L.stage_fc) continue;
     SG_TRY(fold_ln_weight(L.stage_qkv, 3 * D, D, L.ln1_g, L.ln1_b, L.b_qkv, c->hk, L.w_qkv_f, L.c_qkv, L.bf_qkv, as_stream(st)));
     SG_TRY(fold_ln_weight(L.stage_fc, M, D, L.ln2_g, L.ln2_b, L.b_fc, c->hk, L.w_fc_f, L.c_fc, L.bf_fc, as_stream(st)));
-    L.folded = true; any = true;
+    L.folded = true;
   }
   SG_HIP(hipStreamSynchronize(as_stream(st)));               // the staged f32 copies are freed below: their last readers (and writers) are on this stream
   for (auto& L : c->layers) {
