@@ -824,9 +824,11 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
   // strips' LDS round trips on top of that brought nothing: the epilogue is bound by store issue).
   // SPEC == 0 keeps every choice at run time (the rarely used combinations and the row-dot form).
   // SPEC == 4 (MODE 0 only): f32 output + f32 residual, no activation -- the plain residual GEMM (fp8 mode's out-proj, the last block, the text tower).
+  // SPEC == 5 (MODE 0 only): the row-dot form of the JBU tail (sg_jbu_logits) -- 2-byte residual, no activation, nothing stored but the slice sums.
   constexpr bool RES32 = MODE == 0 && SPEC == 4;
-  const int act = SPEC > 0 ? (RES32 ? (int)ACT_NONE : SPEC - 1) : act_rt;
-  const int c_bf16 = (LN || (SPEC > 0 && !PROD && !RES32)) ? 1 : ((PROD || RES32) ? 0 : c_bf16_rt);
+  constexpr bool RDOT = MODE == 0 && SPEC == 5;
+  const int act = SPEC > 0 ? ((RES32 || RDOT) ? (int)ACT_NONE : SPEC - 1) : act_rt;
+  const int c_bf16 = (LN || (SPEC > 0 && !PROD && !RES32 && !RDOT)) ? 1 : ((PROD || RES32 || RDOT) ? 0 : c_bf16_rt);
   constexpr int TN = NI * 16, LDP = TN + 4;
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
   float4 bias4[NI];
@@ -862,14 +864,14 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
     for (int ps = 0; ps < NPASS; ++ps) {
       int m = rb + ps * RPPF + lane / LPRF; m = m < a.M ? m : a.M - 1;
       int n = col0 + (lane % LPRF) * 4; n = n < a.N ? n : a.N - 4;
-      if (SPEC == 0 && a.rowdot && a.rowdot_res_bf16) {   // the JBU tail keeps x in bf16 only (wave-uniform branch)
+      if (RDOT || (SPEC == 0 && a.rowdot && a.rowdot_res_bf16)) {   // the JBU tail keeps x in bf16 only (wave-uniform branch)
         const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(res) + (int64_t)m * a.ldr + n);
         dst[ps] = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
                               __uint_as_float(raw.y & 0xffff0000u));
       } else dst[ps] = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
     }
   };
-  const bool pipe_res = ((PROD && SPEC > 0) || RES32) ? true : (!LN && SPEC == 0 && res != nullptr && !c_bf16);
+  const bool pipe_res = ((PROD && SPEC > 0) || RES32 || RDOT) ? true : (!LN && SPEC == 0 && res != nullptr && !c_bf16);
   if (pipe_res) {
 #pragma unroll
     for (int t = 0; t < RD; ++t) fetch_res(t, rbuf[t]);
@@ -928,7 +930,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           const int r = r0 + lane / LPR, cq = (lane % LPR) * 4;
           const int m = rbase + r, n = col0 + cq;
           float4 x = *reinterpret_cast<const float4*>(patch + r * LDP + cq + pofs);
-          if (SPEC == 0 && !PROD && a.rowdot) {              // row-dot epilogue (wave-uniform): v * (2 r + v) summed over this wave's 64 columns
+          if (RDOT || (SPEC == 0 && !PROD && a.rowdot)) {    // row-dot epilogue (wave-uniform): v * (2 r + v) summed over this wave's 64 columns
             const float4 rr = rbuf[t % RD][r0 / RPP];
             float d = x.x * (2.f * rr.x + x.x) + x.y * (2.f * rr.y + x.y) + x.z * (2.f * rr.z + x.z) + x.w * (2.f * rr.w + x.w);
 #pragma unroll
@@ -1401,6 +1403,8 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
     kern = a.f16 ? gemm_bf16_persist<true, 0, 1> : gemm_bf16_persist<false, 0, 1>;
   } else if (!a.c_is_bf16 && a.residual && !a.rowdot && a.act == ACT_NONE) {
     kern = a.f16 ? gemm_bf16_persist<true, 0, 4> : gemm_bf16_persist<false, 0, 4>;
+  } else if (a.rowdot && a.rowdot_res_bf16 && !a.f16 && a.act == ACT_NONE) {
+    kern = gemm_bf16_persist<false, 0, 5>;
   } else {
     kern = a.f16 ? gemm_bf16_persist<true, 0, 0> : gemm_bf16_persist<false, 0, 0>;
   }
