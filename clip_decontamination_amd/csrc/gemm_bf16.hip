@@ -149,13 +149,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
 // tile goes through a private LDS patch (row stride TN+4 floats: conflict-free 16-byte writes) and comes back row-contiguous, so a
 // store instruction writes WHOLE 128-byte lines (8 rows x 128 B bf16, 4 rows x 256 B f32); bias / activation are applied before
 // the patch, the f32 residual is added on the way out with equally coalesced loads.
-// SPEC > 0 fixes the hot combinations of the fp8 linears at compile time (as gemm_bf16_persist's epilogue does): 1 = 2-byte output, no
-// activation (QKV); 2 / 3 = MXFP8 output after QuickGELU / GELU (fc); 4 = f32 output + f32 residual, no activation (proj).
+// SPEC > 0 fixes the hot combinations at compile time (as gemm_bf16_persist's epilogue does): 1 = 2-byte output, no activation (QKV);
+// 2 / 3 = MXFP8 output after QuickGELU / GELU (fp8 fc); 4 = f32 output + f32 residual, no activation (out-proj, proj);
+// 6 / 7 = 2-byte output after QuickGELU / GELU (fc on the small-launch path).
 template <int MI, int NI, bool F16 = false, int SPEC = 0>
 __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act_rt, int c_bf16_rt, int z, int row0,
                                                int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
-  const int act = SPEC == 0 ? act_rt : (SPEC == 2 ? (int)ACT_QUICK_GELU : SPEC == 3 ? (int)ACT_GELU : (int)ACT_NONE);
+  const int act = SPEC == 0 ? act_rt : ((SPEC == 2 || SPEC == 6) ? (int)ACT_QUICK_GELU : (SPEC == 3 || SPEC == 7) ? (int)ACT_GELU : (int)ACT_NONE);
   const int c_bf16 = SPEC == 0 ? c_bf16_rt : (SPEC != 4);
   const bool mx_out = SPEC == 0 ? a.c_mx != nullptr : (SPEC == 2 || SPEC == 3);
   const float* res = (SPEC == 0 || SPEC == 4) ? (a.residual ? a.residual + (int64_t)z * a.strideC : nullptr) : nullptr;
@@ -1541,7 +1542,15 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
       case 1: rc = launch_ring<128, 128, 2, 2, 3>(a, vec, s); break;
       case 2: rc = launch_ring<256, 128, 4, 2, 3>(a, vec, s); break;
       case 3: rc = launch_ring<256, 256, 2, 4, 2>(a, vec, s); break;
-      case 4: rc = a.f16 ? launch_ring<128, 128, 2, 2, 2, 0, 64, false, true>(a, vec, s) : launch_ring<128, 128, 2, 2, 2>(a, vec, s); break;
+      case 4: {                                             // 128 x 128 tiles: small shapes and small launches; hot epilogue combinations specialised
+        const int sp = !vec || a.c_mx || a.row_scale || a.col_scale ? 0
+                     : (a.c_is_bf16 && !a.residual) ? (a.act == ACT_NONE ? 1 : a.act == ACT_QUICK_GELU ? 6 : 7)
+                     : (!a.c_is_bf16 && a.residual && a.act == ACT_NONE) ? 4 : 0;
+#define SG_RING128(SP) (a.f16 ? launch_ring<128, 128, 2, 2, 2, 0, 64, false, true, false, SP>(a, vec, s) : launch_ring<128, 128, 2, 2, 2, 0, 64, false, false, false, SP>(a, vec, s))
+        rc = sp == 1 ? SG_RING128(1) : sp == 4 ? SG_RING128(4) : sp == 6 ? SG_RING128(6) : sp == 7 ? SG_RING128(7) : SG_RING128(0);
+#undef SG_RING128
+        break;
+      }
       case 5: rc = launch_ring<256, 128, 4, 2, 2>(a, vec, s); break;
       case 6: rc = launch_ring<128, 256, 2, 4, 3>(a, vec, s); break;
       case 7: rc = launch_pingpong(a, vec, s); break;
