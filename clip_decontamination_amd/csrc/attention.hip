@@ -87,8 +87,11 @@ __device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u
 // MULTI = several separately soft-maxed streams are summed (SCLIP / SegEarth / GEM); otherwise no second accumulator.
 // Lean variants are capped at 256 registers (VGPR-form MFMA, 2+ waves per SIMD); the register-hungry ones (bias + multi-stream,
 // head_dim > 64) may take the whole file rather than spill.
-template <int DH, int TS, bool GENERIC, bool MULTI, bool F16, bool PV>
-__global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC || MULTI || DH > 80))) ? 1 : 2) void attn_kernel(AttnArgs a) {
+// GK: 0 = lean (nothing added to the scores), 1 = generic with every option at run time (bias, Gaussian factors, re-softmax, causal mask),
+// 2 = the 'Experimental' last block at compile time: similarity-map bias + re-softmax, no mask, no Gaussian factors.
+template <int DH, int TS, int GK, bool MULTI, bool F16, bool PV>
+__global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 || MULTI || DH > 80))) ? 1 : 2) void attn_kernel(AttnArgs a) {
+  constexpr bool GENERIC = GK != 0, EXPER = GK == 2;
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = TS * KT * C::K_LD + KT * C::V_LD;                 // elements per LDS buffer: [TS K tiles][V tile]
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
   const int nq = (a.N + QB - 1) / QB;
   const int xw = blockIdx.x & 7, jw = blockIdx.x >> 3;
   int b, hd, qb;
-  if (GENERIC && a.bias != nullptr) {
+  if (GENERIC && (EXPER || a.bias != nullptr)) {
     const int unit = (jw / a.H) * 8 + xw;
     if (unit >= a.B * nq) return;
     b = unit / nq; qb = unit % nq; hd = jw % a.H;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
   const int n_streams = MULTI ? a.n_terms : 1;
   const int64_t head_off = (int64_t)b * a.sb + (int64_t)hd * DH;
   const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + (int64_t)hd * DH;
-  const float lse1_2 = (GENERIC && a.resoftmax) ? a.lse_in[((int64_t)b * a.H + hd) * a.N + q_ld] * LOG2E : 0.f;
+  const float lse1_2 = (GENERIC && (EXPER || a.resoftmax)) ? a.lse_in[((int64_t)b * a.H + hd) * a.N + q_ld] * LOG2E : 0.f;
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;               // transposed-read lane roles
 
   const RowMap<DH> kmap = make_row_map<DH>(a.st, a.N, tid), vmap = make_row_map<DH>(a.v_st, a.N, tid);
@@ -197,12 +200,12 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
     float bnext[GENERIC ? 32 : 1];
     const float bias_rn = (GENERIC && a.bias_rn) ? a.bias_rn[((int64_t)b * a.H + hd) * a.N + q_ld] : 1.f;
     auto fetch_bias = [&](int kbase) {
-      if (GENERIC && a.bias) {
+      if (GENERIC && (EXPER || a.bias)) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = kbase + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
           float bvv = (key >= 1 && key < a.N && q_ld >= 1) ? a.bias[(int64_t)b * a.bias_bstride + (int64_t)(key - 1) * n + (q_ld - 1)] : 0.f;
-          if (a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
+          if (!EXPER && a.bias_cn) bvv *= a.bias_cn[((int64_t)b * a.H + hd) * a.N + (key < a.N ? key : a.N - 1)] * bias_rn;   // Gaussian variants: |q_i| |k_j|
           bnext[i] = bvv;
         }
       }
@@ -266,10 +269,10 @@ __global__ __launch_bounds__(256, ((GENERIC && MULTI) || (DH > 64 && (GENERIC ||
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int key = k0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * h;
-          const float bv = a.bias ? bnext[i] * a.bias_w : 0.f;
+          const float bv = (EXPER || a.bias) ? bnext[i] * a.bias_w : 0.f;
           float v = sacc[i >> 4][i & 15] * c2;
-          if (a.resoftmax) v = (__builtin_amdgcn_exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
-          sc[i] = (key < a.N && !(a.causal && key > q_glob)) ? v : -INFINITY;   // causal: text tower (build_causal_mask)
+          if (EXPER || a.resoftmax) v = (__builtin_amdgcn_exp2f(v - lse1_2) + bv) * LOG2E; else v += bv * LOG2E;
+          sc[i] = (key < a.N && !(!EXPER && a.causal && key > q_glob)) ? v : -INFINITY;   // causal: text tower (build_causal_mask)
         }
         if (BIAS_AHEAD && has_next) fetch_bias(k0 + KT);   // lands under this tile's softmax / PV and the next tile's QK^T
         mloc = sc[0];
@@ -402,9 +405,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   constexpr bool CAN_MULTI = TS == 1;
   SG_REQUIRE(CAN_MULTI || !multi, "attention: summed terms and separate streams are exclusive");
   using Kern = void (*)(AttnArgs);
-  const Kern kern = a.ctx ? (generic ? (multi ? attn_kernel<DH, TS, true, CAN_MULTI, AF16, true> : attn_kernel<DH, TS, true, false, AF16, true>)
-                                     : (multi ? attn_kernel<DH, TS, false, CAN_MULTI, AF16, true> : attn_kernel<DH, TS, false, false, AF16, true>))
-                          : (generic ? attn_kernel<DH, TS, true, false, AF16, false> : attn_kernel<DH, TS, false, false, AF16, false>);
+  const bool exper = generic && a.bias && a.resoftmax && !a.causal && !a.bias_cn && !a.bias_rn && !multi && a.ctx;
+  const Kern kern = exper ? attn_kernel<DH, TS, 2, false, AF16, true>
+                  : a.ctx ? (generic ? (multi ? attn_kernel<DH, TS, 1, CAN_MULTI, AF16, true> : attn_kernel<DH, TS, 1, false, AF16, true>)
+                                     : (multi ? attn_kernel<DH, TS, 0, CAN_MULTI, AF16, true> : attn_kernel<DH, TS, 0, false, AF16, true>))
+                          : (generic ? attn_kernel<DH, TS, 1, false, AF16, false> : attn_kernel<DH, TS, 0, false, AF16, false>);
   SG_REQUIRE(a.ctx || !multi, "attention: a log-sum-exp-only pass has one stream");
   if (lds > 64 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t nqb = cdiv(a.N, QB);
