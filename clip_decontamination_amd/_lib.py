@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsegearth_hip.so")
+# SEGEARTH_HIP_LIB: another build of the same library (same-box A/B measurements of a kernel change); the default is the in-tree build
+LIB_PATH = os.environ.get("SEGEARTH_HIP_LIB") or os.path.join(HERE, "libsegearth_hip.so")
 
 # enums (include/segearth_hip.h)
 PREC_F32, PREC_BF16, PREC_FP8, PREC_F16 = 0, 1, 2, 3

@@ -12,6 +12,7 @@
 // of one output row: bias / residual / store are 8- or 16-byte vector accesses, no transpose.
 // Double-buffered LDS, one barrier per K tile.
 #include "common.h"
+#include <type_traits>
 
 namespace sg {
 
@@ -1082,7 +1083,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nt; ++kt, ++s) {
+    // One K step.  STEADY: every piece this step requests (K tiles s+2 / s+3) still belongs to the CURRENT output tile and the stream is
+    // far from its end -- no source select, no end-of-stream test, constant wait counts; the last three steps of a tile take the general form.
+    int kt = 0;
+    auto kstep = [&](auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;
       const char* tA = lds + (s & 3) * TILE_B;
       const char* tW = tA + PBM * KT32 * 2;
       // READ(s)
@@ -1090,8 +1095,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
       for (int jj = 0; jj < 4; ++jj) fw[jj] = read_frag32(tW, 64 * wi + 16 * jj + (lane & 15), lane >> 4);
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = read_frag32(tA, 128 * g + 16 * i + (lane & 15), lane >> 4);
-      if (g == 0) { load_w(s + 2); load_a(s + 3); }
-      else { load_a(s + 3); load_w(s + 3); wait_tile(s + 1); }
+      if constexpr (STEADY) {
+        auto piece = [&](const bf16_t* const (&src)[2], const int (&dst)[2], int ahead) {
+          char* base = lds + ((s + ahead) & 3) * TILE_B;
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + (kt + ahead) * KT32), (lds_ptr_t)(base + dst[p]), 16, 0, 0);
+        };
+        if (g == 0) { piece(cur.w, w_dst, 2); piece(cur.a, a_dst, 3); }
+        else { piece(cur.a, a_dst, 3); piece(cur.w, w_dst, 3); wait_vmcnt<8>(); }
+      } else {
+        if (g == 0) { load_w(s + 2); load_a(s + 3); }
+        else { load_a(s + 3); load_w(s + 3); wait_tile(s + 1); }
+      }
       SG_PS_SYNC();
       // MFMA(s)
       __builtin_amdgcn_s_setprio(1);
@@ -1100,9 +1116,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma_16x16x32<F16>(fw[jj], fa[i], acc[i][jj]);
       __builtin_amdgcn_s_setprio(0);
-      if (g == 0) wait_tile(s + 1);
+      if (g == 0) { if constexpr (STEADY) wait_vmcnt<6>(); else wait_tile(s + 1); }
       SG_PS_SYNC();
-    }
+      ++kt; ++s;
+    };
+    // (the producer instantiation, EPI 2, keeps the general form throughout: measured 1.5 % slower with the split, the others 2 % faster)
+    if constexpr (EPI != 2) { for (; kt + 3 < nt; ) kstep(std::true_type{}); }
+    for (; kt < nt; ) kstep(std::false_type{});
     // ---- tile end ----
     if (g == 0) SG_PS_SYNC();                               // align: every read of this tile's last K tile has retired
     {
