@@ -131,6 +131,15 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x)); }
 __device__ __forceinline__ float quick_gelu_exact(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }
 __device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The 2-byte / fp8 GEMM epilogues (whose results are rounded to 8-11 mantissa bits anyway): erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute) on the hardware exp2 / rcp -- about a third of erff's instructions.  Parity mode keeps erff.
+__device__ __forceinline__ float erf_gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erf(|x| / sqrt 2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;                                                   // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
+}
 
 enum Act { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (ACT == ACT_QUICK_GELU) v[e] = quick_gelu(v[e]);
-          if (ACT == ACT_GELU) v[e] = erf_gelu(v[e]);
+          if (ACT == ACT_GELU) v[e] = erf_gelu_fast(v[e]);
         }
         if (res) {
           const float4 r = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
           float x = v[e];
           if (a.bias) x += a.bias[n + e];
           if (ACT == ACT_QUICK_GELU) x = quick_gelu(x);
-          if (ACT == ACT_GELU) x = erf_gelu(x);
+          if (ACT == ACT_GELU) x = erf_gelu_fast(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
           if (C_BF16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = f2bf(x);
           else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
       } else if (act == ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = erf_gelu_fast(v[e]);
       }
       *reinterpret_cast<float4*>(patch + (lane & 15) * LDP + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
           for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
         } else if (act == ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = erf_gelu_fast(v[e]);
         }
         if (res) {
           const float4 r = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
           float x = v[e];
           if (a.bias) x += a.bias[n + e];
           if (act == ACT_QUICK_GELU) x = quick_gelu(x);
-          else if (act == ACT_GELU) x = erf_gelu(x);
+          else if (act == ACT_GELU) x = erf_gelu_fast(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
           if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
           else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
           for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
         } else if (act == ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = erf_gelu_fast(v[e]);
         }
         if (res) {
           const float4 r = *reinterpret_cast<const float4*>(res + (int64_t)m * a.ldr + n);
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
           float x = v[e];
           if (a.bias) x += a.bias[n + e];
           if (act == ACT_QUICK_GELU) x = quick_gelu(x);
-          else if (act == ACT_GELU) x = erf_gelu(x);
+          else if (act == ACT_GELU) x = erf_gelu_fast(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
           if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
           else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
@@ -897,7 +897,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
       } else if (act == ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = erf_gelu_fast(v[e]);
       }
       v4[j] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -1173,7 +1173,7 @@ __device__ __forceinline__ void epilogue_store8_fp8(f32x4 (&acc)[MI][NI], const 
       for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
     } else if (act == ACT_GELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+      for (int e = 0; e < 4; ++e) v[e] = erf_gelu_fast(v[e]);
     }
     return make_float4(v[0], v[1], v[2], v[3]);
   };
