@@ -95,10 +95,13 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
 // of projected guidance vectors once (41 kB at r = 5) instead of fetching 121 x 128 B per pixel through L1/L2; a wave then walks its
 // 16 pixels with the d*d taps on the lanes, reading centre and neighbour vectors from LDS (row stride 36 floats: conflict-free b128).
 constexpr int JK_LD = KEY_DIM + 4;
-__global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int H, int W, int r,
+// RT = the window radius at compile time (3: JBUStack, 5: JBUOne; 0 = run time), FAST = the throughput-mode arithmetic and bf16 operand copy.
+template <int RT, bool FAST>
+__global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int H, int W, int r_rt,
                                                                const float* __restrict__ range_temp, const float* __restrict__ sigma,
                                                                float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16) {
   extern __shared__ __attribute__((aligned(16))) float jk_sm[];
+  const int r = RT > 0 ? RT : r_rt;
   const int d = 2 * r + 1, d2 = d * d, ldx = d2 + 3, WT = AC_T + 2 * r;
   const int tiles_x = (W + AC_T - 1) / AC_T;
   const int ty0 = (blockIdx.x / tiles_x) * AC_T, tx0 = (blockIdx.x % tiles_x) * AC_T;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], o, 64)); mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], o, 64)); }
     float ex[2][2], s1[2], s2v[2];
-    const bool fast = X16 != nullptr;                          // throughput mode: hardware exp2 / rcp (1 ulp) -- the result is rounded to bf16 anyway
+    constexpr bool fast = FAST;                                // throughput mode: hardware exp2 / rcp (1 ulp) -- the result is rounded to bf16 anyway
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       if (fast) {
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
       if (lane < d2) xr[lane] = k0;
       if (lane + 64 < d2) xr[lane + 64] = k1;
       if (lane < 3) xr[d2 + lane] = gs[pix * 3 + lane];
-      if (X16) {                                               // [taps | guidance | zero padding] as the bf16 A operand of the fixup GEMM
+      if (FAST) {                                              // [taps | guidance | zero padding] as the bf16 A operand of the fixup GEMM
         bf16_t* x16 = X16 + pix * ldx16;
         if (lane < ldx16) x16[lane] = f2bf(lane < d2 ? k0 : (lane < d2 + 3 ? gs[pix * 3 + (lane - d2)] : 0.f));
         const int t2 = lane + 64;
@@ -834,9 +837,12 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
     {
       const int WT = AC_T + 2 * r;
       const size_t lds = (size_t)WT * WT * JK_LD * sizeof(float);
-      SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_tiled_kernel), 64 * 1024));
       SG_REQUIRE(lds <= 64 * 1024, "sg_jbu_upsample: window %d too large", d);
-      hipLaunchKernelGGL(jbu_kernel_tiled_kernel, dim3((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B), dim3(256), lds, s, p.proj, p.gs, oh,
+      using JK = void (*)(const float*, const float*, int, int, int, const float*, const float*, float*, bf16_t*, int);
+      const JK jk = fast ? (r == 5 ? jbu_kernel_tiled_kernel<5, true> : r == 3 ? jbu_kernel_tiled_kernel<3, true> : jbu_kernel_tiled_kernel<0, true>)
+                         : jbu_kernel_tiled_kernel<0, false>;
+      SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jk), 64 * 1024));
+      hipLaunchKernelGGL(jk, dim3((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B), dim3(256), lds, s, p.proj, p.gs, oh,
                          ow, r, S.range_temp, S.sigma, p.X, fast ? p.X16 : nullptr, KP1);
       SG_LAUNCH_CHECK();
     }
