@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32", "fp8"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32", "fp8", "f16x2"],
                     help="bf16 = the headline configuration; f16 = IEEE f16 operands at the same MFMA rate (the reference's own GPU arithmetic); "
                          "f32 = parity mode; fp8 = ordinary-block linears on fp8 MFMA (reported separately, never the default)")
     ap.add_argument("--tile-cols", type=int, default=TILE_COLS, help="tiles per scene row")

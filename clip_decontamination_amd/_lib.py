@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGEARTH_HIP_LIB") or os.path.join(HERE, "libsegearth_hip.so")
 
 # enums (include/segearth_hip.h)
-PREC_F32, PREC_BF16, PREC_FP8, PREC_F16 = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_FP8, PREC_F16, PREC_F16X2 = 0, 1, 2, 3, 4
 MODEL_TYPES = {"vanilla": 0, "MaskCLIP": 1, "ClearCLIP": 2, "SCLIP": 3, "SegEarth": 4, "SFP": 5, "Experimental": 6,
                "NACLIP": 7, "NOnly": 8, "GAV": 9, "GEM": 10}
 IMG_F32_NCHW, IMG_U8_NHWC = 0, 1

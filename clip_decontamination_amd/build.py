@@ -20,11 +20,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsegearth_hip.so")
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "attention_f16.hip", "rowops.hip", "patchify.hip", "refine.hip",
+SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "attention_f16.hip", "attention_h2.hip", "rowops.hip", "patchify.hip", "refine.hip",
            "head.hip", "jbu.hip", "ctd.hip"]
 # the attention loops count vector-issue slots between MFMAs: SLP-packed v_pk_add_f32 / v_pk_mul_f32 cost several plain f32 ops there
 # (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'), so the scalar f32 arithmetic of those units stays scalar
-EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "attention_f16.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "attention_f16.hip": ["-fno-slp-vectorize"], "attention_h2.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 

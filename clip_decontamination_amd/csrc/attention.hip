@@ -17,14 +17,22 @@
 // the kernels, so the two translation units instantiate different symbols.
 #include "rowops.h"
 
+// A THIRD compilation (attention_h2.hip, SG_ATTN_H2 = 1) is the two-plane f16 form of SG_PREC_F16X2 (common.h h2_t): every operand is
+// hi + lo, every product three f16 MFMAs (K_hi.Q_hi + K_lo.Q_hi + K_hi.Q_lo; V_hi.P_hi + V_lo.P_hi + V_hi.P_lo) into the same f32
+// accumulators, the probabilities are split into two planes in registers -- f32-grade scores and contexts at a third of the MFMA rate.
 #ifndef SG_ATTN_F16
 #define SG_ATTN_F16 0
+#endif
+#ifndef SG_ATTN_H2
+#define SG_ATTN_H2 0
 #endif
 
 namespace sg {
 
-constexpr bool AF16 = SG_ATTN_F16 != 0;
+constexpr bool AH2 = SG_ATTN_H2 != 0;
+constexpr bool AF16 = SG_ATTN_F16 != 0 || AH2;
 int attention_f16_impl(const AttnArgs& a, hipStream_t s);      // defined by the SG_ATTN_F16 translation unit
+int attention_h2_impl(const AttnArgs& a, hipStream_t s);       // defined by the SG_ATTN_H2 translation unit
 
 constexpr int QB = 128;        // queries per workgroup
 constexpr int KT = 64;         // keys per LDS tile
@@ -33,12 +41,19 @@ constexpr float RESCALE_TAU = 8.0f;   // log2 units: probabilities may reach 2^8
 typedef __attribute__((ext_vector_type(4))) short short4_;
 typedef __attribute__((address_space(3))) short4_* lds_s4_ptr;
 
+// Two-plane form (AH2): a head row is PW = 2 DH f16 in HBM ([8 hi | 8 lo] groups; the host passes strides in f16 units).  In LDS the planes
+// are DE-INTERLEAVED (store_rows): a K row is [DH hi | DH lo] (+8 pad: the 16-row ds_read_b128 stays conflict-free, row stride 17 / 21 / ...
+// 16-byte slots), a V row [DVT*32 hi | DVT*32 lo] (+32 pad: 80 / 112 / ... dwords = 16 mod 64, so the four rows of a transposed read
+// cover four disjoint 16-dword bank groups) -- the fragment reads of one plane are exactly the plain kernel's.
 template <int DH> struct AttnCfg {
   static constexpr int KS = DH / 16;                 // k-steps of the score MFMA
   static constexpr int DVT = (DH + 31) / 32;         // 32-row tiles of O^T
-  static constexpr int K_LD = DH + 8;                // LDS row strides (elements): conflict-free ds_read_b128 of 16 rows
-  static constexpr int V_LD = DVT * 32 + 32;         //   and 4-row ds_read_b64_tr_b16 blocks (48-dword stride at dh 64)
-  static constexpr int CH = DH / 8;                  // 16-byte chunks per row
+  static constexpr int PW = AH2 ? 2 * DH : DH;       // 2-byte elements per head row in HBM
+  static constexpr int K_LO = DH;                    // AH2: offset of the lo plane inside an LDS row
+  static constexpr int V_LO = DVT * 32;
+  static constexpr int K_LD = PW + 8;                // LDS row strides (elements): conflict-free ds_read_b128 of 16 rows
+  static constexpr int V_LD = (AH2 ? 2 : 1) * DVT * 32 + 32;   //   and 4-row ds_read_b64_tr_b16 blocks (48-dword stride at dh 64)
+  static constexpr int CH = PW / 8;                  // 16-byte chunks per row
   static constexpr int NL = (KT * CH + 255) / 256;   // chunks per thread per tile
 };
 
@@ -73,13 +88,16 @@ __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, int64_
     reg[i] = *reinterpret_cast<const u32x4*>(src + (o < m.omax[i] ? o : m.omax[i]));
   }
 }
+// lo_off (AH2): HBM chunk 2 g + p of a row (plane p of storage group g) goes to LDS column p * lo_off + 8 g
 template <int DH>
-__device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u32x4 (&reg)[AttnCfg<DH>::NL]) {
+__device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u32x4 (&reg)[AttnCfg<DH>::NL], int lo_off) {
   constexpr int CH = AttnCfg<DH>::CH;
 #pragma unroll
   for (int i = 0; i < AttnCfg<DH>::NL; ++i) {
     const int idx = tid + i * 256;
-    if (idx < KT * CH) *reinterpret_cast<u32x4*>(lds + (idx / CH) * ld + (idx % CH) * 8) = reg[i];
+    const int cc = idx % CH;
+    const int col = AH2 ? (cc & 1) * lo_off + (cc >> 1) * 8 : cc * 8;
+    if (idx < KT * CH) *reinterpret_cast<u32x4*>(lds + (idx / CH) * ld + col) = reg[i];
   }
 }
 
@@ -89,13 +107,18 @@ __device__ __forceinline__ void store_rows(bf16_t* lds, int ld, int tid, const u
 // head_dim > 64) may take the whole file rather than spill.
 // GK: 0 = lean (nothing added to the scores), 1 = generic with every option at run time (bias, Gaussian factors, re-softmax, causal mask),
 // 2 = the 'Experimental' last block at compile time: similarity-map bias + re-softmax, no mask, no Gaussian factors.
-template <int DH, int TS, int GK, bool MULTI, bool F16, bool PV>
-__global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 || MULTI || DH > 80))) ? 1 : 2) void attn_kernel(AttnArgs a) {
+// H2: nothing but a name -- the two-plane translation unit instantiates the SAME <DH, TS, GK, MULTI, F16 = true, PV> combinations as the f16 one
+// with different bodies (AH2 is a file-level constant), so it must not share their symbols.
+template <int DH, int TS, int GK, bool MULTI, bool F16, bool PV, bool H2 = AH2>
+// (two-plane form: twice the fragment registers -- the variants with a bias / two summed terms and every head_dim > 64 get the whole file too)
+__global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 || MULTI || DH > 80)) || (AH2 && (DH > 64 || (GK != 0 && TS == 2)))) ? 1 : 2) void attn_kernel(AttnArgs a) {
   constexpr bool GENERIC = GK != 0, EXPER = GK == 2;
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = TS * KT * C::K_LD + KT * C::V_LD;                 // elements per LDS buffer: [TS K tiles][V tile]
-  bf16_t* sbuf = reinterpret_cast<bf16_t*>(smem);                       // [2][BUF]
+  constexpr int NB = (size_t)2 * BUF * sizeof(bf16_t) > 160 * 1024 ? 1 : 2;   // two buffers unless they exceed the CU's LDS (two-plane form, two
+                                                                        // summed terms at head_dim 128): then ONE buffer and a second barrier per tile
+  bf16_t* sbuf = reinterpret_cast<bf16_t*>(smem);                       // [NB][BUF]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   // XCD-aware order: workgroup w runs on XCD w % 8 (dispatch round-robin; used for speed only).  All query blocks of one
@@ -124,8 +147,8 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
   constexpr bool do_pv = PV;                                                   // a context is wanted (false: the log-sum-exp pass alone) -- a template
                                                                                // parameter, so that the key-tile loop is free of run-time branches
   const int n_streams = MULTI ? a.n_terms : 1;
-  const int64_t head_off = (int64_t)b * a.sb + (int64_t)hd * DH;
-  const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + (int64_t)hd * DH;
+  const int64_t head_off = (int64_t)b * a.sb + (int64_t)hd * C::PW;
+  const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + (int64_t)hd * C::PW;
   const float lse1_2 = (GENERIC && (EXPER || a.resoftmax)) ? a.lse_in[((int64_t)b * a.H + hd) * a.N + q_ld] * LOG2E : 0.f;
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;               // transposed-read lane roles
 
@@ -144,12 +167,18 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
   for (int sidx = 0; sidx < n_streams; ++sidx) {
     const bf16_t* kptr[TS];
     bf16x8 qf[TS][C::KS];                                    // B port: lane = query, 8 consecutive k per half-wave
+    bf16x8 qfl[AH2 ? TS : 1][AH2 ? C::KS : 1];               // AH2: the lo plane of the same 8 k values
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
       kptr[t] = a.k[a.sum_scores ? t : sidx] + head_off;
       const bf16_t* qp = a.q[a.sum_scores ? t : sidx] + head_off + (int64_t)q_ld * a.st;
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + h * 8);
+      for (int ks = 0; ks < C::KS; ++ks) {
+        if constexpr (AH2) {                                 // storage group 2 ks + h: 32 bytes = [8 hi | 8 lo]
+          qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + (2 * ks + h) * 16);
+          qfl[t][ks] = *reinterpret_cast<const bf16x8*>(qp + (2 * ks + h) * 16 + 8);
+        } else qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + h * 8);
+      }
     }
     if (!GENERIC) {
       // Lean path: Q is pre-multiplied by scale * log2(e) (rounded back to bf16 once per stream) and the score accumulator starts at
@@ -158,7 +187,15 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
       for (int t = 0; t < TS; ++t)
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-          if constexpr (F16) {
+          if constexpr (AH2) {                               // (hi + lo) * c2 in f32, split again
+            const f16x8 hq = __builtin_bit_cast(f16x8, qf[t][ks]), lq = __builtin_bit_cast(f16x8, qfl[t][ks]);
+            float fq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fq[j] = ((float)hq[j] + (float)lq[j]) * c2;
+            uint4 nh, nl;
+            split_h2x8(fq, nh, nl);
+            qf[t][ks] = __builtin_bit_cast(bf16x8, nh); qfl[t][ks] = __builtin_bit_cast(bf16x8, nl);
+          } else if constexpr (F16) {
             const f16x8 hq = __builtin_bit_cast(f16x8, qf[t][ks]);
             f32x8_t fq;
 #pragma unroll
@@ -175,7 +212,7 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
 #pragma unroll
     for (int t = 0; t < TS; ++t)
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[t][ks]));
+      for (int ks = 0; ks < C::KS; ++ks) { asm volatile("" : "+v"(qf[t][ks])); if constexpr (AH2) asm volatile("" : "+v"(qfl[t][ks])); }
 #pragma unroll
     for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
@@ -187,8 +224,8 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
     for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, 0, kmap, kreg[t]);
     if (do_pv) load_rows<DH>(vbase, a.v_st, 0, vmap, vreg);
 #pragma unroll
-    for (int t = 0; t < TS; ++t) store_rows<DH>(sbuf + t * KT * C::K_LD, C::K_LD, tid, kreg[t]);
-    if (do_pv) store_rows<DH>(sbuf + TS * KT * C::K_LD, C::V_LD, tid, vreg);
+    for (int t = 0; t < TS; ++t) store_rows<DH>(sbuf + t * KT * C::K_LD, C::K_LD, tid, kreg[t], C::K_LO);
+    if (do_pv) store_rows<DH>(sbuf + TS * KT * C::K_LD, C::V_LD, tid, vreg, C::V_LO);
     __syncthreads();
     int cur = 0;
 
@@ -218,12 +255,38 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
         for (int t = 0; t < TS; ++t) load_rows<DH>(kptr[t], a.st, k0 + KT, kmap, kreg[t]);
         if (do_pv) load_rows<DH>(vbase, a.v_st, k0 + KT, vmap, vreg);
       }
-      const bf16_t* sK = sbuf + cur * BUF;
+      const bf16_t* sK = sbuf + (NB == 2 ? cur * BUF : 0);
       const bf16_t* sV = sK + TS * KT * C::K_LD;
 
       // ---- scores of the whole 64-key tile: S^T[key][query], 2 sub-blocks x KS k-steps -----------------------------
       f32x16 sacc[2];
       {
+        const float s_init = (!GENERIC && m_run != -INFINITY) ? -m_run : 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[sub][r] = s_init;
+        if constexpr (AH2) {
+          // two-plane form: the fragments of one k-step at a time (both planes, both key sub-blocks = 16 registers), three MFMAs each
+#pragma unroll
+          for (int t = 0; t < TS; ++t)
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+              bf16x8 kh[2], kl[2];
+#pragma unroll
+              for (int sub = 0; sub < 2; ++sub) {
+                const bf16_t* kp = sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8;
+                kh[sub] = *reinterpret_cast<const bf16x8*>(kp);
+                kl[sub] = *reinterpret_cast<const bf16x8*>(kp + C::K_LO);
+              }
+#pragma unroll
+              for (int sub = 0; sub < 2; ++sub) sacc[sub] = mfma_32x32x16<true>(kh[sub], qf[t][ks], sacc[sub]);
+#pragma unroll
+              for (int sub = 0; sub < 2; ++sub) sacc[sub] = mfma_32x32x16<true>(kl[sub], qf[t][ks], sacc[sub]);
+#pragma unroll
+              for (int sub = 0; sub < 2; ++sub) sacc[sub] = mfma_32x32x16<true>(kh[sub], qfl[t][ks], sacc[sub]);
+            }
+        } else {
         bf16x8 kf[2][TS][C::KS];                           // all K fragments of the tile first: one exposed LDS latency, not eight
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -232,11 +295,6 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks)
               kf[sub][t][ks] = *reinterpret_cast<const bf16x8*>(sK + t * KT * C::K_LD + (sub * 32 + c) * C::K_LD + ks * 16 + h * 8);
-        const float s_init = (!GENERIC && m_run != -INFINITY) ? -m_run : 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sacc[sub][r] = s_init;
 #pragma unroll
         for (int t = 0; t < TS; ++t)
 #pragma unroll
@@ -244,12 +302,20 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)              // the two key sub-blocks alternate: no MFMA waits on its predecessor
               sacc[sub] = mfma_32x32x16<F16>(kf[sub][t][ks], qf[t][ks], sacc[sub]);
+        }
       }
       // (b) V^T fragments of the tile are fetched NOW (transposed LDS reads, lane 4q+p of a 16-lane group addresses row q,
       // cols 4p..4p+3) so their latency hides under the softmax arithmetic below.
       typedef __attribute__((ext_vector_type(8))) short short8_;
-      short8_ vfr[C::DVT][4];
-      if (do_pv) {
+      short8_ vfr[AH2 ? 1 : C::DVT][AH2 ? 1 : 4];
+      auto read_vt = [&](int t, int f, int plane) -> short8_ {   // V^T fragment (d-tile t, key step f) of one plane
+        const int key0 = f * 16 + 4 * h;
+        const bf16_t* p0 = sV + (key0 + qq) * C::V_LD + plane * C::V_LO + t * 32 + 16 * (g & 1) + 4 * pp;
+        const short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0));
+        const short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0 + 8 * C::V_LD));
+        return (short8_){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      };
+      if (do_pv && !AH2) {
 #pragma unroll
         for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
@@ -337,9 +403,15 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
       l_run += lsum;
       // P (bf16) is already the B operand: element j of k-step s2 of sub-block sub = sc[16 sub + 8 s2 + j]
       bf16x8 pf[4];                                          // (bit pattern: f16 values when F16; probabilities are <= 2^RESCALE_TAU)
+      bf16x8 pfl[AH2 ? 4 : 1];                               // AH2: the lo plane of the probabilities
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        if constexpr (F16) {
+        if constexpr (AH2) {
+          const float p8[8] = {sc[8 * f], sc[8 * f + 1], sc[8 * f + 2], sc[8 * f + 3], sc[8 * f + 4], sc[8 * f + 5], sc[8 * f + 6], sc[8 * f + 7]};
+          uint4 ph, pl;
+          split_h2x8(p8, ph, pl);
+          pf[f] = __builtin_bit_cast(bf16x8, ph); pfl[f] = __builtin_bit_cast(bf16x8, pl);
+        } else if constexpr (F16) {
           f32x8_t fp;                                        // 4 x v_cvt_pk_f16_f32
 #pragma unroll
           for (int j = 0; j < 8; ++j) fp[j] = sc[8 * f + j];
@@ -349,18 +421,34 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
           for (int j = 0; j < 8; ++j) pf[f][j] = (__bf16)sc[8 * f + j];
         }
       }
-      if (do_pv) {
+      if constexpr (AH2) {
+        if (do_pv) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            short8_ vh[C::DVT], vl[C::DVT];
+#pragma unroll
+            for (int t = 0; t < C::DVT; ++t) { vh[t] = read_vt(t, f, 0); vl[t] = read_vt(t, f, 1); }
+#pragma unroll
+            for (int t = 0; t < C::DVT; ++t) o_acc[t] = mfma_32x32x16<true>(*reinterpret_cast<bf16x8*>(&vh[t]), pf[f], o_acc[t]);
+#pragma unroll
+            for (int t = 0; t < C::DVT; ++t) o_acc[t] = mfma_32x32x16<true>(*reinterpret_cast<bf16x8*>(&vl[t]), pf[f], o_acc[t]);
+#pragma unroll
+            for (int t = 0; t < C::DVT; ++t) o_acc[t] = mfma_32x32x16<true>(*reinterpret_cast<bf16x8*>(&vh[t]), pfl[f], o_acc[t]);
+          }
+        }
+      } else if (do_pv) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int t = 0; t < C::DVT; ++t)                 // alternate the d-blocks of O^T for the same reason
             o_acc[t] = mfma_32x32x16<F16>(*reinterpret_cast<bf16x8*>(&vfr[t][f]), pf[f], o_acc[t]);
       }
+      if (NB == 1) __syncthreads();                          // single buffer: every wave is done reading the tile before it is overwritten
       if (has_next) {                                        // the other buffer was last read one iteration ago
-        bf16_t* nK = sbuf + (cur ^ 1) * BUF;
+        bf16_t* nK = sbuf + (NB == 2 ? (cur ^ 1) * BUF : 0);
 #pragma unroll
-        for (int t = 0; t < TS; ++t) store_rows<DH>(nK + t * KT * C::K_LD, C::K_LD, tid, kreg[t]);
-        if (do_pv) store_rows<DH>(nK + TS * KT * C::K_LD, C::V_LD, tid, vreg);
+        for (int t = 0; t < TS; ++t) store_rows<DH>(nK + t * KT * C::K_LD, C::K_LD, tid, kreg[t], C::K_LO);
+        if (do_pv) store_rows<DH>(nK + TS * KT * C::K_LD, C::V_LD, tid, vreg, C::V_LO);
       }
       __syncthreads();
       cur ^= 1;
@@ -378,7 +466,7 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
 
   if (a.lse_out && h == 0 && q_glob < a.N) a.lse_out[((int64_t)b * a.H + hd) * a.N + q_glob] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
   if (do_pv && q_glob < a.N) {
-    bf16_t* op = a.ctx + (int64_t)b * a.ctx_sb + (int64_t)q_glob * a.ctx_st + (int64_t)hd * DH;
+    bf16_t* op = a.ctx + (int64_t)b * a.ctx_sb + (int64_t)q_glob * a.ctx_st + (int64_t)hd * C::PW;
 #pragma unroll
     for (int t = 0; t < C::DVT; ++t)
 #pragma unroll
@@ -387,6 +475,15 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
         if (dv < DH) {
           uint2 o;
           const f32x16& of = MULTI ? o_tot[t] : o_acc[t];
+          if constexpr (AH2) {                               // elements dv .. dv+3 of storage group dv / 8: hi at [4 h, 4 h + 4), lo 8 elements on
+            uint2 ol;
+            split_h2(of[4 * g4 + 0] * a.out_scale, of[4 * g4 + 1] * a.out_scale, o.x, ol.x);
+            split_h2(of[4 * g4 + 2] * a.out_scale, of[4 * g4 + 3] * a.out_scale, o.y, ol.y);
+            bf16_t* gp = op + (dv >> 3) * 16 + (dv & 7);
+            *reinterpret_cast<uint2*>(gp) = o;
+            *reinterpret_cast<uint2*>(gp + 8) = ol;
+            continue;
+          }
           o.x = pack_half2<F16>(of[4 * g4 + 0] * a.out_scale, of[4 * g4 + 1] * a.out_scale);
           o.y = pack_half2<F16>(of[4 * g4 + 2] * a.out_scale, of[4 * g4 + 3] * a.out_scale);
           *reinterpret_cast<uint2*>(op + dv) = o;
@@ -398,7 +495,8 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
 template <int DH, int TS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<DH>;
-  const size_t lds = (size_t)2 * (TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
+  const size_t lds2 = (size_t)2 * (TS * KT * C::K_LD + KT * C::V_LD) * sizeof(bf16_t);
+  const size_t lds = lds2 > 160 * 1024 ? lds2 / 2 : lds2;                 // the kernel's NB
   const bool generic = a.bias != nullptr || a.resoftmax != 0 || a.causal != 0;
   const bool multi = !a.sum_scores && a.n_terms > 1;
   // TS == 2 means two SUMMED score terms = one stream: the multi-stream variants exist for TS == 1 only
@@ -426,10 +524,13 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   return SG_OK;
 }
 
-#if SG_ATTN_F16
+#if SG_ATTN_H2
+int attention_h2_impl(const AttnArgs& a, hipStream_t s) {   // strides arrive in f16 units (the caller doubled the element strides)
+#elif SG_ATTN_F16
 int attention_f16_impl(const AttnArgs& a, hipStream_t s) {
 #else
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
+  if (a.h2) return attention_h2_impl(a, s);
   if (a.f16) return attention_f16_impl(a, s);
 #endif
   SG_REQUIRE(a.n_terms >= 1 && a.n_terms <= 3, "attention: n_terms=%d", a.n_terms);
@@ -453,7 +554,7 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
 #undef SG_ATTN_CASE
 }
 
-#if !SG_ATTN_F16
+#if !SG_ATTN_F16 && !SG_ATTN_H2
 // ---- head-averaged statistics for outlier detection ------------------------------------------------------
 // One wave per token j: for every head, s_cls = scale * q[0].k[j], s_diag = scale * q[j].k[j];
 // probabilities are recovered from the per-row log-sum-exp the attention kernel wrote.
@@ -473,9 +574,9 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(const T* __restrict__ q
   for (int hd = 0; hd < H; ++hd) {
     float dc = 0.f, dd = 0.f;
     for (int d = lane; d < dh; d += 64) {
-      const float kv = to_f32<T>(kj[hd * dh + d]);
-      dc += to_f32<T>(q0[hd * dh + d]) * kv;
-      dd += to_f32<T>(qj[hd * dh + d]) * kv;
+      const float kv = ld_elem<T>(kj, hd * dh + d);
+      dc += ld_elem<T>(q0, hd * dh + d) * kv;
+      dd += ld_elem<T>(qj, hd * dh + d) * kv;
     }
     dc = wave_sum(dc); dd = wave_sum(dd);
     const float* l = lse + ((int64_t)b * H + hd) * N;
@@ -541,7 +642,7 @@ int attention_stats(const void* qkv, int is_bf16, int64_t sb, int64_t st, const 
   const bool aligned = (sb % 8 == 0) && (st % 8 == 0) && ((((uintptr_t)qkv) & 15) == 0);
 #define SG_STATS_FAST(LPH, F)                                                                                                      \
   hipLaunchKernelGGL((attn_stats_fast_kernel<LPH, F>), grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, scale, attn_cls, attn_diag)
-  if (is_bf16 && aligned && (dh == 32 || dh == 64 || dh == 128)) {
+  if (is_bf16 && is_bf16 != HK_F16X2 && aligned && (dh == 32 || dh == 64 || dh == 128)) {
     const bool h = is_bf16 == HK_F16;
     if (dh == 32) { if (h) SG_STATS_FAST(4, true); else SG_STATS_FAST(4, false); }
     else if (dh == 64) { if (h) SG_STATS_FAST(8, true); else SG_STATS_FAST(8, false); }
@@ -550,12 +651,13 @@ int attention_stats(const void* qkv, int is_bf16, int64_t sb, int64_t st, const 
     return SG_OK;
   }
 #undef SG_STATS_FAST
-  if (is_bf16 == HK_F16) hipLaunchKernelGGL(attn_stats_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
+  if (is_bf16 == HK_F16X2) hipLaunchKernelGGL(attn_stats_kernel<h2_t>, grid, dim3(256), 0, s, (const h2_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
+  else if (is_bf16 == HK_F16) hipLaunchKernelGGL(attn_stats_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
   else if (is_bf16) hipLaunchKernelGGL(attn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
   else hipLaunchKernelGGL(attn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, sb, st, lse, N, H, dh, scale, attn_cls, attn_diag);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }
-#endif  // !SG_ATTN_F16
+#endif  // !SG_ATTN_F16 && !SG_ATTN_H2
 
 }  // namespace sg

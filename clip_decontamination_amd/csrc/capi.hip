@@ -33,15 +33,18 @@ struct ProfState {
 static thread_local ProfState g_prof;
 
 static std::mutex g_dev_mu;                                        // guards the two per-device caches below
-static std::vector<std::pair<int, const void*>> g_lds_done;        // (device, kernel) pairs already opted in
+struct LdsOptIn { int dev; const void* kernel; size_t bytes; };
+static std::vector<LdsOptIn> g_lds_done;                           // (device, kernel) -> the dynamic-LDS size already opted in to
 static std::vector<std::pair<int, int>> g_cu_count;               // (device, compute units)
 int ensure_dynamic_lds(const void* kernel, size_t bytes) {
   int dev = 0;
   SG_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  for (const auto& e : g_lds_done) if (e.first == dev && e.second == kernel) return SG_OK;
+  LdsOptIn* hit = nullptr;
+  for (auto& e : g_lds_done) if (e.dev == dev && e.kernel == kernel) hit = &e;
+  if (hit && hit->bytes >= bytes) return SG_OK;                   // a LARGER request than the cached one raises the limit again (jbu_pixel_logits_kernel: size depends on C)
   SG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  g_lds_done.emplace_back(dev, kernel);
+  if (hit) hit->bytes = bytes; else g_lds_done.push_back(LdsOptIn{dev, kernel, bytes});
   return SG_OK;
 }
 int device_cu_count() {
@@ -158,7 +161,8 @@ static int attn_generic(int bf16, const AttnSpec& sp, int B, int N, int H, int d
     a.v = (const bf16_t*)sp.v; a.sb = sp.sb; a.st = sp.st; a.v_sb = sp.v_sb; a.v_st = sp.v_st;
     a.n_terms = sp.n_terms; a.sum_scores = sp.sum_scores; a.causal = sp.causal;
     a.B = B; a.N = N; a.H = H; a.dh = dh; a.scale = sp.scale; a.scale_per_image = sp.scale_per_image;
-    a.out_scale = sp.out_scale; a.ctx_sb = sp.ctx_sb; a.ctx_st = sp.ctx_st; a.f16 = bf16 == HK_F16;
+    a.out_scale = sp.out_scale; a.ctx_sb = sp.ctx_sb; a.ctx_st = sp.ctx_st; a.f16 = bf16 == HK_F16; a.h2 = bf16 == HK_F16X2;
+    if (a.h2) { a.sb *= 2; a.st *= 2; a.v_sb *= 2; a.v_st *= 2; a.ctx_sb *= 2; a.ctx_st *= 2; }   // two-plane f16: the kernel addresses in f16 units
     if (sp.resoftmax) {
       AttnArgs p = a; p.ctx = nullptr; p.bias = nullptr; p.lse_out = buf.lse1; p.resoftmax = 0;
       SG_TRY(attention_bf16(p, s));
@@ -203,7 +207,7 @@ static int run_attention(int bf16, const void* qkv, int B, int N, int D, int H, 
   const int dh = D / H;
   Variant v;
   if (!variant_of(model_type, v)) return fail(SG_ERR_INVALID, "attention variant %d is not built (NACLIP / NOnly / GAV: SURVEY.md §8f rank 3)", model_type);
-  const size_t e = bf16 ? 2 : 4;
+  const size_t e = hk_esz(bf16);
   AttnSpec sp{};
   for (int t = 0; t < v.n_terms; ++t) { sp.q[t] = (const char*)qkv + (size_t)v.qsel[t] * D * e; sp.k[t] = (const char*)qkv + (size_t)v.ksel[t] * D * e; }
   sp.v = (const char*)qkv + (size_t)2 * D * e;
@@ -234,7 +238,7 @@ static int linear(int bf16, const void* A, int64_t lda, const void* W, const flo
     GemmBf16Args g{};
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
     g.C = C; g.ldc = ldc; g.c_is_bf16 = c_f32 ? 0 : 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f;
-    g.f16 = bf16 == HK_F16;
+    g.f16 = bf16 == HK_F16; g.h2 = bf16 == HK_F16X2;
     return gemm_bf16(g, s);
   }
   GemmF32Args g{};
@@ -287,9 +291,10 @@ __global__ void zero_diag_kernel(float* sim, int n, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) sim[(i / n) * (int64_t)n * n + (i % n) * (int64_t)(n + 1)] = 0.f;
 }
-__global__ void unpack_bf16_kernel(const bf16_t* src, float* dst, int64_t n, int f16) {
+// `kind` = HalfKind of src (two-plane f16: a contiguous buffer whose rows are multiples of 8 elements, so flat index = element index)
+__global__ void unpack_bf16_kernel(const bf16_t* src, float* dst, int64_t n, int kind) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = f16 ? h2f(f16_t{src[i]}) : bf2f(src[i]);
+  if (i < n) dst[i] = kind == HK_F16X2 ? ld_elem<h2_t>(reinterpret_cast<const h2_t*>(src), i) : kind == HK_F16 ? h2f(f16_t{src[i]}) : bf2f(src[i]);
 }
 
 // similarity map from L2-normalised patch rows xhat [B,n,D] (compute dtype) -> sim [B,n,n] f32
@@ -298,7 +303,7 @@ static int similarity_from_xhat(int bf16, const void* xhat, int B, int n, int D,
     GemmBf16Args g{};
     g.A = (const bf16_t*)xhat; g.lda = D; g.strideA = (int64_t)n * D; g.W = (const bf16_t*)xhat; g.ldw = D; g.strideW = (int64_t)n * D;
     g.C = sim; g.ldc = n; g.strideC = (int64_t)n * n; g.c_is_bf16 = 0; g.M = n; g.N = n; g.K = D; g.batch = B; g.act = 0;
-    g.alpha = 1.0f / temperature; g.f16 = bf16 == HK_F16;
+    g.alpha = 1.0f / temperature; g.f16 = bf16 == HK_F16; g.h2 = bf16 == HK_F16X2;
     SG_TRY(gemm_bf16(g, s));
   } else {
     GemmF32Args g{};
@@ -345,7 +350,7 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.hbuf = b.take(R * d.mlp_width * e);
   p.x8 = p.h8 = p.hmx = nullptr; p.sx8 = p.sh8 = nullptr;
   p.ln_slice = p.ln_rows = nullptr;
-  if (c->hk && !c->fp8 && d.width % 64 == 0) { p.ln_slice = b.get<float>(R * (d.width / 64) * 2); p.ln_rows = b.get<float>(R * 2); }
+  if ((c->hk == HK_BF16 || c->hk == HK_F16) && !c->fp8 && d.width % 64 == 0) { p.ln_slice = b.get<float>(R * (d.width / 64) * 2); p.ln_rows = b.get<float>(R * 2); }
   if (c->fp8) {
     p.x8 = (uint8_t*)b.take(R * d.width); p.sx8 = b.get<float>(R);
     p.h8 = (uint8_t*)b.take(R * d.mlp_width); p.sh8 = b.get<float>(R);
@@ -476,7 +481,8 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
   const sg_vit_desc& d = *desc;
   SG_REQUIRE(d.width > 0 && d.layers >= 2 && d.heads > 0 && d.width % d.heads == 0 && d.patch > 0 && d.embed_dim > 0 && d.grid0 > 0 &&
              d.mlp_width > 0, "sg_create: bad descriptor");
-  SG_REQUIRE(d.precision == SG_PREC_F32 || d.precision == SG_PREC_BF16 || d.precision == SG_PREC_FP8 || d.precision == SG_PREC_F16, "sg_create: bad precision %d", d.precision);
+  SG_REQUIRE(d.precision == SG_PREC_F32 || d.precision == SG_PREC_BF16 || d.precision == SG_PREC_FP8 || d.precision == SG_PREC_F16 ||
+             d.precision == SG_PREC_F16X2, "sg_create: bad precision %d", d.precision);
   SG_REQUIRE(d.width % 4 == 0 && d.embed_dim % 4 == 0, "sg_create: width / embed_dim must be multiples of 4");
   if (d.precision == SG_PREC_FP8)
     SG_REQUIRE(d.width % 128 == 0 && d.mlp_width % 128 == 0, "sg_create: fp8 mode needs width and mlp_width to be multiples of 128");
@@ -488,8 +494,8 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
   DeviceGuard dg(device);
   sg_context* c = new sg_context();
   c->d = d; c->device = device; c->fp8 = d.precision == SG_PREC_FP8;
-  c->hk = d.precision == SG_PREC_F32 ? HK_F32 : (d.precision == SG_PREC_F16 ? HK_F16 : HK_BF16);
-  c->esz = c->hk ? 2 : 4;
+  c->hk = hk_of_precision(d.precision);
+  c->esz = hk_esz(c->hk);
   c->Kpatch = 3 * d.patch * d.patch;
   c->Kpad = (int)align_up(c->Kpatch, 64);
   c->finalized = false;
@@ -511,7 +517,7 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
       L.b_qkv = bb.get<float>(3 * D); L.b_out = bb.get<float>(D); L.b_fc = bb.get<float>(M); L.b_proj = bb.get<float>(D);
       L.ln1_g = bb.get<float>(D); L.ln1_b = bb.get<float>(D); L.ln2_g = bb.get<float>(D); L.ln2_b = bb.get<float>(D);
       L.w_qkv8 = L.w_fc8 = L.w_proj8 = nullptr; L.s_qkv = L.s_fc = L.s_proj = nullptr;
-      if (c->hk && !c->fp8) {
+      if ((c->hk == HK_BF16 || c->hk == HK_F16) && !c->fp8) {     // folded-LayerNorm operands exist for the 2-byte modes only
         L.w_qkv_f = bb.take((size_t)3 * D * D * e); L.w_fc_f = bb.take((size_t)M * D * e);
         L.c_qkv = bb.get<float>(3 * D); L.bf_qkv = bb.get<float>(3 * D); L.c_fc = bb.get<float>(M); L.bf_fc = bb.get<float>(M);
       }
@@ -714,12 +720,13 @@ static int std_block(sg_context* c, const LayerW& L, float* x, const Plan& p, in
 
 static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan& p, int B, int N, hipStream_t s);
 
-__global__ void unpack_qk_kernel(const bf16_t* __restrict__ qkv, int N, int D, float* __restrict__ out, int f16) {
+__global__ void unpack_qk_kernel(const void* __restrict__ qkv, int N, int D, float* __restrict__ out, int kind) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)N * 2 * D) return;
   const int t = (int)(i / (2 * D)), c = (int)(i % (2 * D));
-  const bf16_t v = qkv[(int64_t)t * 3 * D + c];
-  out[i] = f16 ? h2f(f16_t{v}) : bf2f(v);
+  if (kind == HK_F16X2) { out[i] = ld_elem<h2_t>(reinterpret_cast<const h2_t*>(qkv) + (int64_t)t * 3 * D, c); return; }
+  const bf16_t v = reinterpret_cast<const bf16_t*>(qkv)[(int64_t)t * 3 * D + c];
+  out[i] = kind == HK_F16 ? h2f(f16_t{v}) : bf2f(v);
 }
 // head-averaged attention matrix [B,N,N] of the block whose packed qkv is in p.qkv (the tensor the reference gets from
 // nn.MultiheadAttention(need_weights=True), transformer.py:609-610).  Only the optional mode='attention' enhancer needs it.
@@ -730,8 +737,8 @@ static int averaged_attention(sg_context* c, const Plan& p, int B, int N, hipStr
   if (!c->hk) return head_mean(p.probs, B, H, N, p.attn_avg, s);        // parity mode: the probabilities are materialised already
   const int64_t NN = (int64_t)N * N;
   for (int b = 0; b < B; ++b) {
-    const bf16_t* qkv = (const bf16_t*)p.qkv + (int64_t)b * N * 3 * D;
-    hipLaunchKernelGGL(unpack_qk_kernel, dim3((unsigned)cdiv((int64_t)N * 2 * D, 256)), dim3(256), 0, s, qkv, N, D, p.sa_qk32, c->hk == HK_F16 ? 1 : 0);
+    const void* qkv = (const char*)p.qkv + (size_t)b * N * 3 * D * c->esz;
+    hipLaunchKernelGGL(unpack_qk_kernel, dim3((unsigned)cdiv((int64_t)N * 2 * D, 256)), dim3(256), 0, s, qkv, N, D, p.sa_qk32, c->hk);
     SG_LAUNCH_CHECK();
     GemmF32Args g{};
     g.A = p.sa_qk32; g.lda = 2 * D; g.sAi = dh; g.B = p.sa_qk32 + D; g.sbk = 1; g.sbn = 2 * D; g.sBi = dh;
@@ -775,9 +782,20 @@ extern "C" int sg_vit_forward(sg_context* c, const sg_tile_batch* tiles, const s
   if (gem) {
     const int first = L - (o->gem_depth - 1);
     SG_REQUIRE(o->gem_depth >= 2 && first >= 0, "sg_vit_forward: gem_depth %d does not fit %d layers", o->gem_depth, L);
+    // GEM + outlier suppression in ONE forward (BASELINE configs[2]; the reference cannot run it, SURVEY R5 -- DESIGN.md section 7 defines it):
+    // detection on the head-averaged attention of the ORDINARY stream of block L-2, suppression on the GEM stream before ln_post.
+    // The other refiners have no defined place in the GEM forward: refuse rather than ignore them.
+    SG_REQUIRE(!o->selfattn_enabled && !o->similarity_enabled && !o->layer_fusion_enabled,
+               "sg_vit_forward: GEM composes with outlier suppression only (self-attention / similarity enhancement and layer fusion are not defined for the GEM forward)");
+    const bool gem_out = o->outlier_enabled != 0;
     bool x16 = false;                                                 // p.xn / p.ln_slice describe p.x (folded LayerNorm hand-off between blocks)
-    for (int i = 0; i < first; ++i) SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, false, s, false, false, &x16));
+    for (int i = 0; i < first; ++i) SG_TRY(std_block(c, c->layers[i], p.x, p, B, N, gem_out && i == L - 2, s, false, false, &x16));
     SG_TRY(gem_forward_tail(c, o, p, B, N, s));
+    if (gem_out) {
+      const int k = o->outlier_top_k < n ? o->outlier_top_k : n;
+      SG_TRY(select_topk(p.attn_cls, p.attn_diag, B, N, k, 0, p.idx_out, s));
+      SG_TRY(neighbour_refine(p.x_gem, (int64_t)N * D, D, p.idx_out, B, gh, gw, D, k, 1, o->outlier_contamination_temp, p.refine_scratch, s));
+    }
     SG_TRY(layernorm(p.x_gem, D, c->lnpost_g, c->lnpost_b, p.xn, D, c->hk, R, D, 1e-5f, s));
   } else {
     const int mid = (L - 1) / 2;                                      // transformer.py:593
@@ -880,8 +898,11 @@ static int gem_forward_tail(sg_context* c, const sg_forward_opts* o, const Plan&
     const void* xn = p.gem_out;
     if (bf) { SG_TRY(pack_rows(p.gem_out, R, D, D, p.xn, D, bf, s)); xn = p.xn; }
     SG_TRY(linear(bf, xn, D, LW.w_qkv, LW.b_qkv, nullptr, p.qkv, 3 * D, false, (int)R, 3 * D, D, ACT_NONE, s));
-    // ordinary stream attention -> p.ctx
-    SG_TRY(run_attention(bf, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, false, ab, s));
+    // ordinary stream attention -> p.ctx (+ block L-2's head-averaged A[cls,:] / diag(A) when outlier suppression rides on the GEM forward)
+    const bool stats = o->outlier_enabled != 0 && i == L - 2;
+    SG_TRY(run_attention(bf, p.qkv, B, N, D, H, SG_VANILLA, nullptr, 0.f, nullptr, p.ctx, stats, ab, s));
+    if (stats)
+      SG_TRY(attention_stats(p.qkv, bf, (int64_t)N * 3 * D, 3 * D, p.lse, B, N, H, dh, scale, p.attn_cls, p.attn_diag, s));
     // GEM streams (v, k, q): normalise per head -> self-attend with values = the normalised vectors -> normalise
     const int64_t st3 = 3 * (int64_t)D;
     for (int t = 0; t < 3; ++t) {
@@ -953,7 +974,7 @@ extern "C" int sg_text_create(sg_text** out, int device, int width, int layers, 
                               int quick_gelu, int precision) {
   SG_REQUIRE(out && width > 0 && layers > 0 && heads > 0 && width % heads == 0 && context_length > 0 && vocab_size > 0 && embed_dim > 0,
              "sg_text_create: bad arguments");
-  SG_REQUIRE(precision == SG_PREC_F32 || precision == SG_PREC_BF16 || precision == SG_PREC_F16, "sg_text_create: bad precision");
+  SG_REQUIRE(precision == SG_PREC_F32 || precision == SG_PREC_BF16 || precision == SG_PREC_F16 || precision == SG_PREC_F16X2, "sg_text_create: bad precision");
   SG_REQUIRE(width % 4 == 0 && embed_dim % 4 == 0, "sg_text_create: width / embed_dim must be multiples of 4");
   if (precision != SG_PREC_F32) {
     const int dh = width / heads;
@@ -963,7 +984,7 @@ extern "C" int sg_text_create(sg_text** out, int device, int width, int layers, 
   sg_text* t = new sg_text();
   sg_context& c = t->core;
   c.d = sg_vit_desc{width, layers, heads, 1, embed_dim, 1, 4 * width, quick_gelu, precision};
-  c.device = device; c.hk = precision == SG_PREC_F32 ? HK_F32 : (precision == SG_PREC_F16 ? HK_F16 : HK_BF16); c.esz = c.hk ? 2 : 4; c.Kpatch = c.Kpad = 0; c.finalized = false;
+  c.device = device; c.hk = hk_of_precision(precision); c.esz = hk_esz(c.hk); c.fp8 = false; c.Kpatch = c.Kpad = 0; c.finalized = false;
   t->context_length = context_length; t->vocab_size = vocab_size; t->embed_dim = embed_dim;
   auto lay = [&](Bump& bb) {
     const size_t e = c.esz; const int D = width, M = 4 * width;
@@ -1108,12 +1129,13 @@ extern "C" int sg_op_linear(const float* A, const float* W, const float* bias, c
   SG_REQUIRE(A && W && C, "sg_op_linear: null pointer");
   hipStream_t s = as_stream(st);
   if (precision == SG_PREC_F32) return linear(HK_F32, A, K, W, bias, residual, C, N, true, M, N, K, act, s);
-  const int hk = precision == SG_PREC_F16 ? HK_F16 : HK_BF16;
+  const int hk = hk_of_precision(precision);
+  const size_t e = hk_esz(hk);
   const int Kp = (int)align_up(K, 64);
-  const size_t need = align_up((size_t)M * Kp * 2, 256) + (size_t)N * Kp * 2;
+  const size_t need = align_up((size_t)M * Kp * e, 256) + (size_t)N * Kp * e;
   if (!scratch || scratch_bytes < need) return fail(SG_ERR_STATE, "sg_op_linear: scratch %zu < %zu", scratch_bytes, need);
   bf16_t* a16 = (bf16_t*)scratch;
-  bf16_t* w16 = (bf16_t*)((char*)scratch + align_up((size_t)M * Kp * 2, 256));
+  bf16_t* w16 = (bf16_t*)((char*)scratch + align_up((size_t)M * Kp * e, 256));
   SG_TRY(pack_rows(A, M, K, K, a16, Kp, hk, s));
   SG_TRY(pack_rows(W, N, K, K, w16, Kp, hk, s));
   return linear(hk, a16, Kp, w16, bias, residual, C, N, true, M, N, Kp, act, s);
@@ -1157,7 +1179,7 @@ extern "C" int sg_op_ln_chain(const float* A, const float* W1, const float* b1, 
     SG_TRY(linear(hk, xn, D, w216, b2, nullptr, y16, N2, false, M, N2, D, act, s));
   }
   const int64_t total = (int64_t)M * N2;
-  hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)y16, y, total, hk == HK_F16 ? 1 : 0);
+  hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)y16, y, total, hk);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }
@@ -1165,7 +1187,7 @@ extern "C" int sg_op_ln_chain(const float* A, const float* W1, const float* b1, 
 extern "C" size_t sg_op_attention_scratch_bytes(int B, int N, int D, int H, int precision) {
   const size_t R = (size_t)B * N;
   size_t b = 4 * 256 + 2 * align_up((size_t)B * H * N * 4, 256) + align_up((size_t)(N - 1) * (N - 1) * 4, 256) + 2 * align_up((size_t)B * H * N * 4, 256);
-  if (precision != SG_PREC_F32) b += align_up(R * 3 * D * 2, 256) + align_up(R * D * 2, 256);
+  if (precision != SG_PREC_F32) b += align_up(R * 3 * D * hk_esz(hk_of_precision(precision)), 256) + align_up(R * D * hk_esz(hk_of_precision(precision)), 256);
   else b += 2 * align_up((size_t)B * H * N * N * 4, 256);
   return b + 4096;
 }
@@ -1176,13 +1198,13 @@ extern "C" int sg_op_attention(const float* qkv, int B, int N, int D, int H, int
   SG_REQUIRE(D % H == 0, "sg_op_attention: D %% H != 0");
   hipStream_t s = as_stream(st);
   const int64_t R = (int64_t)B * N;
-  const int bf = precision == SG_PREC_F32 ? HK_F32 : (precision == SG_PREC_F16 ? HK_F16 : HK_BF16);
+  const int bf = hk_of_precision(precision);
   Bump b(scratch, scratch_bytes, false);
   AttnBuffers ab{};
   ab.lse = b.get<float>((size_t)B * H * N); ab.lse1 = b.get<float>((size_t)B * H * N);
   ab.omega = b.get<float>((size_t)(N - 1) * (N - 1)); ab.qnorm = b.get<float>((size_t)B * H * N); ab.knorm = b.get<float>((size_t)B * H * N);
   void* qkv_c = (void*)qkv; void* ctx_c = ctx;
-  if (bf) { qkv_c = b.take((size_t)R * 3 * D * 2); ctx_c = b.take((size_t)R * D * 2); }
+  if (bf) { qkv_c = b.take((size_t)R * 3 * D * hk_esz(bf)); ctx_c = b.take((size_t)R * D * hk_esz(bf)); }
   else { ab.scores = b.get<float>((size_t)B * H * N * N); ab.probs = b.get<float>((size_t)B * H * N * N); }
   if (b.off > scratch_bytes) return fail(SG_ERR_STATE, "sg_op_attention: scratch %zu < %zu", scratch_bytes, b.off);
   if (bf) SG_TRY(pack_rows(qkv, R, 3 * D, 3 * D, qkv_c, 3 * D, bf, s));
@@ -1191,7 +1213,7 @@ extern "C" int sg_op_attention(const float* qkv, int B, int N, int D, int H, int
   SG_TRY(run_attention(bf, qkv_c, B, N, D, H, variant, sim, sim_weight, nullptr, ctx_c, stats, ab, s));
   if (stats) SG_TRY(attention_stats(qkv_c, bf, (int64_t)N * 3 * D, 3 * D, ab.lse, B, N, H, D / H, 1.0f / sqrtf((float)(D / H)), attn_cls, attn_diag, s));
   if (bf) {
-    hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, (const bf16_t*)ctx_c, ctx, R * D, bf == HK_F16 ? 1 : 0);
+    hipLaunchKernelGGL(unpack_bf16_kernel, dim3((unsigned)cdiv(R * D, 256)), dim3(256), 0, s, (const bf16_t*)ctx_c, ctx, R * D, bf);
     SG_LAUNCH_CHECK();
   }
   return SG_OK;
@@ -1201,8 +1223,8 @@ extern "C" int sg_similarity_map(const float* patches, int64_t batch_stride, int
                                  int precision, float* sim, void* scratch, size_t scratch_bytes, sg_stream st) {
   SG_REQUIRE(patches && sim && scratch, "sg_similarity_map: null pointer");
   hipStream_t s = as_stream(st);
-  const int bf = precision == SG_PREC_F32 ? HK_F32 : (precision == SG_PREC_F16 ? HK_F16 : HK_BF16);
-  const size_t need = (size_t)B * n * D * (bf ? 2 : 4);
+  const int bf = hk_of_precision(precision);
+  const size_t need = (size_t)B * n * D * hk_esz(bf);
   if (scratch_bytes < need) return fail(SG_ERR_STATE, "sg_similarity_map: scratch %zu < %zu", scratch_bytes, need);
   if (bf) SG_REQUIRE(D % 64 == 0, "sg_similarity_map: bf16 mode needs D %% 64 == 0");
   SG_TRY(l2norm_rows(patches, 0, batch_stride, ld, n, scratch, bf, (int64_t)n * D, D, (int64_t)B * n, D, 1e-12f, s));

@@ -91,8 +91,38 @@ __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
   const f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -F16_MAX, F16_MAX), __builtin_amdgcn_fmed3f(hi, -F16_MAX, F16_MAX)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
-// half-precision kind of a buffer / kernel: 0 = f32, 1 = bf16, 2 = f16 (every `int ..._bf16` flag of the internal ops takes these values)
-enum HalfKind { HK_F32 = 0, HK_BF16 = 1, HK_F16 = 2 };
+// half-precision kind of a buffer / kernel: 0 = f32, 1 = bf16, 2 = f16, 3 = two-plane f16 (every `int ..._bf16` flag of the internal ops takes these values)
+enum HalfKind { HK_F32 = 0, HK_BF16 = 1, HK_F16 = 2, HK_F16X2 = 3 };
+
+// ---- two-plane f16 (SG_PREC_F16X2): x = hi + lo with hi = f16(x), lo = f16(x - hi) -- 22 significant bits on the f16 matrix pipe --------
+// A product A.W^T is issued as A_hi.W_hi + A_hi.W_lo + A_lo.W_hi into ONE f32 accumulator (the lo.lo term is below f32 resolution): three
+// MFMAs per K step, measured at or below the error of an f32 fmaf chain (tools/h2_probe.hip: K = 1024, 4.0e-5 against 6.1e-5 on O(1) data).
+// lo is NOT rescaled: gfx950 converts to f16 subnormals and its f16 MFMA honours subnormal inputs on both ports (same probe), so the
+// representation error of an element is max(2^-22 |x|, 2^-25) -- f32-grade for the O(0.01 .. 100) data of this path.  |x| above 2 * 65504
+// is not representable (both planes saturate); parity mode (SG_PREC_F32) has no such bound.
+// Storage: groups of 8 consecutive elements as [8 x hi f16][8 x lo f16] = 32 bytes, i.e. exactly the f32 footprint; element offsets that
+// are multiples of 8 address like 4-byte elements, so `h2_t` is the pointer-arithmetic type (never dereferenced as a value).  One 32-byte
+// load hands a lane both planes of its 8 K values: the hi and the lo fragment of a v_mfma_f32_16x16x32_f16 / 32x32x16 operand.
+struct h2_t { uint32_t raw; };
+// two f32 -> (packed hi pair, packed lo pair); hi saturates at +-65504, lo carries what is left (saturating too)
+__device__ __forceinline__ void split_h2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f32x2_t v = {__builtin_amdgcn_fmed3f(a, -F16_MAX, F16_MAX), __builtin_amdgcn_fmed3f(b, -F16_MAX, F16_MAX)};
+  const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+  const f32x2_t back = __builtin_convertvector(h, f32x2_t);
+  const f32x2_t r = {__builtin_amdgcn_fmed3f(a - back[0], -F16_MAX, F16_MAX), __builtin_amdgcn_fmed3f(b - back[1], -F16_MAX, F16_MAX)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+}
+// 8 consecutive elements (one storage group) -> the 32 bytes of the group
+__device__ __forceinline__ void split_h2x8(const float (&v)[8], uint4& hi, uint4& lo) {
+  split_h2(v[0], v[1], hi.x, lo.x); split_h2(v[2], v[3], hi.y, lo.y); split_h2(v[4], v[5], hi.z, lo.z); split_h2(v[6], v[7], hi.w, lo.w);
+}
+__device__ __forceinline__ void store_h2x8(h2_t* group, const float (&v)[8]) {      // `group` = address of element 8g of a row
+  uint4 hi, lo; split_h2x8(v, hi, lo);
+  reinterpret_cast<uint4*>(group)[0] = hi; reinterpret_cast<uint4*>(group)[1] = lo;
+}
+static inline int hk_of_precision(int p) { return p == SG_PREC_F32 ? HK_F32 : p == SG_PREC_F16 ? HK_F16 : p == SG_PREC_F16X2 ? HK_F16X2 : HK_BF16; }
+static inline size_t hk_esz(int hk) { return (hk == HK_BF16 || hk == HK_F16) ? 2 : 4; }    // bytes per element of an operand buffer
 template <bool F16> __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) { return F16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); }
 __device__ __forceinline__ uint32_t pack_half2(int kind, float lo, float hi) { return kind == HK_F16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); }
 // MFMA on 2-byte operands held as bf16x8 bit patterns: the f16 forms take the same cycles as the bf16 forms (MI355X_MICROARCH.md)
@@ -113,6 +143,19 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
 template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return f2h(v); }
+// Element i of a row (row kernels that walk a row element by element).  For h2_t the row base must sit on a storage-group boundary
+// (a multiple of 8 elements); the element's planes are 16 bytes apart inside its 32-byte group.
+template <typename T> __device__ __forceinline__ float ld_elem(const T* row, int64_t i) { return to_f32<T>(row[i]); }
+template <> __device__ __forceinline__ float ld_elem<h2_t>(const h2_t* row, int64_t i) {
+  const uint16_t* p = reinterpret_cast<const uint16_t*>(row) + ((i >> 3) << 4) + (i & 7);
+  return h2f(f16_t{p[0]}) + h2f(f16_t{p[8]});
+}
+template <typename T> __device__ __forceinline__ void st_elem(T* row, int64_t i, float v) { row[i] = from_f32<T>(v); }
+template <> __device__ __forceinline__ void st_elem<h2_t>(h2_t* row, int64_t i, float v) {
+  uint16_t* p = reinterpret_cast<uint16_t*>(row) + ((i >> 3) << 4) + (i & 7);
+  const f16_t h = f2h(v);
+  p[0] = h.bits; p[8] = f2h(v - h2f(h)).bits;
+}
 
 // ---- wave-level reductions (64 lanes) ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -145,7 +188,7 @@ enum Act { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
 
 // ---- optional live kernel timing (bench.py roofline): HIP events around the launches of one kernel family ----
 enum ProfCat { PROF_GEMM_BF16 = 0, PROF_ATTENTION = 1, PROF_GEMM_F32 = 2, PROF_GEMM_PERSIST = 3, PROF_GEMM_FP8 = 4, PROF_GEMM_PERSIST_LN_CONSUMER = 5,
-               PROF_GEMM_PERSIST_LN_PRODUCER = 6, PROF_NCAT = 7 };   // 5 / 6: the persistent kernel's folded-LayerNorm instantiations (sg_profile_read(3) includes them)   // 3: the persistent bf16 kernel alone (the dominant kernel bench.py prices)
+               PROF_GEMM_PERSIST_LN_PRODUCER = 6, PROF_GEMM_H2 = 7, PROF_NCAT = 8 };   // 7: the two-plane f16 GEMM (work = ALGORITHMIC 2 M N K; the kernel issues 3x that on the matrix pipe)   // 5 / 6: the persistent kernel's folded-LayerNorm instantiations (sg_profile_read(3) includes them)   // 3: the persistent bf16 kernel alone (the dominant kernel bench.py prices)
 bool prof_on();
 void prof_begin(int cat, double work, hipStream_t s);   // work = algorithmic FLOPs of the launch
 void prof_end(int cat, hipStream_t s);
@@ -159,6 +202,8 @@ struct GemmBf16Args {
   const float* residual; int64_t ldr;                 // f32 [M,N] or null (batch stride = strideC)
   void* C; int64_t ldc; int64_t strideC; int c_is_bf16;   // C: 0 = f32, 1 = the operands' 2-byte type (bf16, or f16 when `f16` is set)
   int f16;                                            // operands (and a 2-byte C) are IEEE f16 instead of bf16: SG_PREC_F16
+  int h2;                                             // SG_PREC_F16X2: A, W (and C when c_is_bf16) are two-plane f16 (h2_t: 4 bytes per element, lda / ldw / ldc /
+                                                      // strides in ELEMENTS, multiples of 8); K % 32 == 0; exact activations; no folded-LayerNorm / row-dot / fp8 forms
   int M, N, K, batch, act;
   float alpha;                                        // applied to the accumulator before bias
   // fp8 mode (fp8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K % 128 == 0); lda / ldw / K stay in ELEMENTS (= bytes);

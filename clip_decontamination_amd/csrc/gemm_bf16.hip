@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
 // SPEC > 0 fixes the hot combinations at compile time (as gemm_bf16_persist's epilogue does): 1 = 2-byte output, no activation (QKV);
 // 2 / 3 = MXFP8 output after QuickGELU / GELU (fp8 fc); 4 = f32 output + f32 residual, no activation (out-proj, proj);
 // 6 / 7 = 2-byte output after QuickGELU / GELU (fc on the small-launch path).
-template <int MI, int NI, bool F16 = false, int SPEC = 0>
+// SPLIT (SG_PREC_F16X2): a "2-byte" C is the two-plane f16 form (8 columns = one 32-byte storage group per lane, 256 contiguous bytes per
+// row and instruction); activations are the exact forms of parity mode (expf / erff), not the hardware-approximation ones.
+template <int MI, int NI, bool F16 = false, int SPEC = 0, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act_rt, int c_bf16_rt, int z, int row0,
                                                int col0, float* patch, int lane) {
   constexpr int TN = NI * 16, LDP = TN + 4;
@@ -180,10 +182,10 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
                     acc[i][j][2] * (al * cs4[j].z) + bias4[j].z, acc[i][j][3] * (al * cs4[j].w) + bias4[j].w};
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? quick_gelu_exact(v[e]) : quick_gelu(v[e]);
       } else if (act == ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = erf_gelu_fast(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? erf_gelu(v[e]) : erf_gelu_fast(v[e]);
       }
       *reinterpret_cast<float4*>(patch + (lane & 15) * LDP + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -219,6 +221,11 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
         } else if (r < 16 && m < a.M && n < a.N) {
           const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
           const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
+          if constexpr (SPLIT) {
+            const float v8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            store_h2x8(reinterpret_cast<h2_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n, v8);
+            continue;
+          }
           uint4 o; o.x = pack_half2<F16>(x0.x, x0.y); o.y = pack_half2<F16>(x0.z, x0.w); o.z = pack_half2<F16>(x1.x, x1.y); o.w = pack_half2<F16>(x1.z, x1.w);
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
         }
@@ -263,8 +270,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // The legacy v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate on gfx950 (tools/mfma_rate.hip: 2.1 vs 4.8 PFLOP/s), so it is not used.
 // MXA (fp8 only): A carries MX block scales (GemmBf16Args::a_mx): every K tile stages one more piece -- the dwords holding the four E8M0
 // scales of each A row -- behind the operand image, and the MFMA's second scale operand gets the lane's own byte.
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false, int SPEC = 0>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
+// SPLIT (SG_PREC_F16X2): the operands are two-plane f16 rows seen as f16 matrices of twice the width (host side: K, lda, ldw doubled), so a
+// 128-byte K tile holds 32 elements as four [8 hi | 8 lo] groups.  The SOURCE-side chunk permutation also de-interleaves the planes: LDS
+// chunks 0-3 of a row are the four hi chunks, 4-7 the four lo chunks -- the fragment reads are then exactly the plain kernel's kk = 0 / 1
+// reads (conflict-free as they stand), and a K tile is ONE k-step of three MFMAs: W_hi.A_hi + W_lo.A_hi + W_hi.A_lo.
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false, int SPEC = 0, bool SPLIT = false>   // ABLATE (tuning only): 1 = no loads in the loop, 2 = no MFMA
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a, int act, int c_bf16, int vec) {
+  static_assert(!SPLIT || (BKT == 64 && F16 && !FP8 && !MXA), "two-plane f16: 128-byte K tiles on the f16 MFMA");
   constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MI = TM / 16, NI = TN / 16;
   constexpr int RPS = BKT == 64 ? 8 : 16;                // rows per 1 KiB slab (row = BKT * 2 bytes)
   constexpr int SLABS = (BM_ + BN_) / RPS;               // 1 KiB slabs per K tile
@@ -301,7 +313,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
       const int c = BKT == 64 ? (lane & 7) : (lane & 3);
       const bool is_a = slab * RPS < BM_;
       const int rl = is_a ? r : r - BM_;                   // the swizzle is a function of the row inside its own tile
-      const int gch = BKT == 64 ? (c ^ ((rl >> 1) & 7)) : (c ^ swz32(rl));
+      int gch = BKT == 64 ? (c ^ ((rl >> 1) & 7)) : (c ^ swz32(rl));
+      if constexpr (SPLIT) gch = ((gch & 3) << 1) | (gch >> 2);   // logical chunk (plane p, group g) = 4 p + g lives at global chunk 2 g + p
       const bf16_t* src;
       if (is_a) { int gr = m0 + r; gr = gr < a.M ? gr : a.M - 1; src = A + (int64_t)gr * a.lda + t * BKT + gch * 8; }
       else { int gr = n0 + rl; gr = gr < a.N ? gr : a.N - 1; src = W + (int64_t)gr * a.ldw + t * BKT + gch * 8; }
@@ -364,6 +377,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw8[j].v, fa8[i].v, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       continue;
     }
+    if constexpr (SPLIT) {
+      bf16x8 fah[MI], fal[MI], fwh[NI], fwl[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        fwh[j] = read_frag(bufW, wave_n * TN + j * 16 + (lane & 15), lane >> 4);
+        fwl[j] = read_frag(bufW, wave_n * TN + j * 16 + (lane & 15), 4 + (lane >> 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        fah[i] = read_frag(bufA, wave_m * TM + i * 16 + (lane & 15), lane >> 4);
+        fal[i] = read_frag(bufA, wave_m * TM + i * 16 + (lane & 15), 4 + (lane >> 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = mfma_16x16x32<true>(fwh[j], fah[i], acc[i][j]);
+          acc[i][j] = mfma_16x16x32<true>(fwl[j], fah[i], acc[i][j]);
+          acc[i][j] = mfma_16x16x32<true>(fwh[j], fal[i], acc[i][j]);
+        }
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < BKT / 32; ++kk) {
       const int chunk = kk * 4 + (lane >> 4);
@@ -394,9 +429,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
   }
   if (vec) {                                               // N % 8 == 0, aligned: coalesced path through an LDS patch
     __syncthreads();                                       // every wave is done reading the staging buffers
-    epilogue_store<MI, NI, F16, SPEC>(acc, a, act, c_bf16, z, m0 + wave_m * TM, n0 + wave_n * TN, reinterpret_cast<float*>(lds) + wave * 16 * (TN + 4), lane);
+    epilogue_store<MI, NI, F16, SPEC, SPLIT>(acc, a, act, c_bf16, z, m0 + wave_m * TM, n0 + wave_n * TN, reinterpret_cast<float*>(lds) + wave * 16 * (TN + 4), lane);
     return;
   }
+  // scalar path (ragged N / unaligned C): f32 C only in SPLIT mode (checked on the host), exact activations there
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -445,8 +481,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
           if (n + e >= a.N) break;
           float x = v[e];
           if (a.bias) x += a.bias[n + e];
-          if (act == ACT_QUICK_GELU) x = quick_gelu(x);
-          else if (act == ACT_GELU) x = erf_gelu_fast(x);
+          if (act == ACT_QUICK_GELU) x = SPLIT ? quick_gelu_exact(x) : quick_gelu(x);
+          else if (act == ACT_GELU) x = SPLIT ? erf_gelu(x) : erf_gelu_fast(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
           if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
           else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
@@ -471,7 +507,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
 //   * RAW: every wave drains its own loads (vmcnt(0)) at the end of MFMA(t,3) (slot 8t+7 / 8t+8) before the barrier; the first
 //     readers of another group's rows come >= 1 slot after that barrier (group 0 reads group-1-loaded W rows in READ(t+1,1),
 //     slot 8t+10; group 1 reads group-0-loaded W rows in READ(t+1,0), slot 8t+9).
-template <bool F16>
+// SPLIT (SG_PREC_F16X2): as in gemm_bf16_ring -- the planes are de-interleaved by the source-side chunk permutation, fragment [.][0] is the
+// hi plane and [.][1] the lo plane of the tile's 32 elements, and a phase issues 8 x 3 MFMAs (W_hi.A_hi + W_lo.A_hi + W_hi.A_lo).
+template <bool F16, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int act, int c_bf16, int vec) {
   constexpr int PBM = 256, PBN = 256;
   constexpr int BUF_BYTES = (PBM + PBN) * BK * 2;          // 64 KiB
@@ -497,8 +535,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
     const int rw = 64 * wi + 32 * g + 8 * p + sub;                        // row inside the W tile
     int gra = m0 + ra; gra = gra < a.M ? gra : a.M - 1;
     int grw = n0 + rw; grw = grw < a.N ? grw : a.N - 1;
-    a_src[p] = A + (int64_t)gra * a.lda + ((cpos ^ ((ra >> 1) & 7)) << 3);
-    w_src[p] = W + (int64_t)grw * a.ldw + ((cpos ^ ((rw >> 1) & 7)) << 3);
+    int ca = cpos ^ ((ra >> 1) & 7), cw = cpos ^ ((rw >> 1) & 7);
+    if constexpr (SPLIT) { ca = ((ca & 3) << 1) | (ca >> 2); cw = ((cw & 3) << 1) | (cw >> 2); }   // logical chunk 4 p + g <- global chunk 2 g + p
+    a_src[p] = A + (int64_t)gra * a.lda + (ca << 3);
+    w_src[p] = W + (int64_t)grw * a.ldw + (cw << 3);
     a_dst[p] = (128 * g + 32 * wi + 8 * p) * 128;                         // wave-uniform slab base
     w_dst[p] = PBM * BK * 2 + (64 * wi + 32 * g + 8 * p) * 128;
   }
@@ -535,11 +575,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
 #define SG_PP_MFMA(MH, NH)                                                                               \
   do {                                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                       \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
+    _Pragma("unroll") for (int kk = 0; kk < (SPLIT ? 3 : 2); ++kk)                                       \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
           acc[4 * (MH) + i][2 * (NH) + j] =                                                              \
-              mfma_16x16x32<F16>(fw[j][kk], fa[i][kk], acc[4 * (MH) + i][2 * (NH) + j]); \
+              mfma_16x16x32<F16>(fw[j][SPLIT ? (kk == 1) : kk], fa[i][SPLIT ? (kk == 2) : kk], acc[4 * (MH) + i][2 * (NH) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                       \
   } while (0)
 #define SG_PP_SYNC()                                 \
@@ -588,7 +628,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
 
   if (vec) {
     __syncthreads();
-    epilogue_store<8, 4, F16>(acc, a, act, c_bf16, z, m0 + 128 * g, n0 + 64 * wi, reinterpret_cast<float*>(lds) + wave * 16 * 68, lane);
+    epilogue_store<8, 4, F16, 0, SPLIT>(acc, a, act, c_bf16, z, m0 + 128 * g, n0 + 64 * wi, reinterpret_cast<float*>(lds) + wave * 16 * 68, lane);
     return;
   }
   const float* res = a.residual ? a.residual + (int64_t)z * a.strideC : nullptr;
@@ -631,8 +671,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
           if (n + e >= a.N) break;
           float x = v[e];
           if (a.bias) x += a.bias[n + e];
-          if (act == ACT_QUICK_GELU) x = quick_gelu(x);
-          else if (act == ACT_GELU) x = erf_gelu_fast(x);
+          if (act == ACT_QUICK_GELU) x = SPLIT ? quick_gelu_exact(x) : quick_gelu(x);
+          else if (act == ACT_GELU) x = SPLIT ? erf_gelu(x) : erf_gelu_fast(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
           if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
           else reinterpret_cast<float*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = x;
@@ -644,7 +684,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
 
 static int launch_pingpong(const GemmBf16Args& a, int vec, hipStream_t s) {
   const size_t lds = 2 * (256 + 256) * BK * 2;
-  auto kern = a.f16 ? gemm_bf16_pingpong<true> : gemm_bf16_pingpong<false>;
+  auto kern = a.h2 ? gemm_bf16_pingpong<true, true> : a.f16 ? gemm_bf16_pingpong<true> : gemm_bf16_pingpong<false>;
   SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
@@ -937,7 +977,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
             float d = x.x * (2.f * rr.x + x.x) + x.y * (2.f * rr.y + x.y) + x.z * (2.f * rr.z + x.z) + x.w * (2.f * rr.w + x.w);
 #pragma unroll
             for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
-            if ((lane % LPR) == 0 && m < a.M) a.rowdot[(int64_t)m * a.rowdot_ld + (col0 >> 6)] = d;
+            if ((lane % LPR) == 0 && m < a.M && col0 < a.N) a.rowdot[(int64_t)m * a.rowdot_ld + (col0 >> 6)] = d;   // col0 >= N: a wave past the last 64-column slice (N % 256 != 0) owns no slot
             continue;
           }
           if (pipe_res) {
@@ -967,7 +1007,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           const float e0 = y0.x - mu, e1 = y0.y - mu, e2 = y0.z - mu, e3 = y0.w - mu, e4 = y1.x - mu, e5 = y1.y - mu, e6 = y1.z - mu, e7 = y1.w - mu;
           float sq = ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7));
           sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-          if ((lane & 7) == 0 && m8 < a.M)
+          if ((lane & 7) == 0 && m8 < a.M && col0 < a.N)      // col0 >= N (N % 256 != 0): this wave's slice does not exist -- its slot would be row m8+1's
             *reinterpret_cast<float2*>(a.row_stats + ((int64_t)m8 * (a.N >> 6) + (col0 >> 6)) * 2) = make_float2(sm, sq);
         }
       }
@@ -1465,9 +1505,9 @@ void set_gemm_config(int c) {
 }
 
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false, int SPEC = 0>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int ABLATE = 0, int BKT = 64, bool FP8 = false, bool F16 = false, bool MXA = false, int SPEC = 0, bool SPLIT = false>
 static int launch_ring(const GemmBf16Args& a, int vec, hipStream_t s) {
-  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8, F16, MXA, SPEC>;
+  auto kern = gemm_bf16_ring<BM_, BN_, WM, WN, STAGES, ABLATE, BKT, FP8, F16, MXA, SPEC, SPLIT>;
   const size_t lds = (size_t)STAGES * ((BM_ + BN_) * BKT * 2 + (MXA ? BM_ * 4 : 0));
   if (lds > 48 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
@@ -1527,8 +1567,32 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
   return SG_OK;
 }
 
+// SG_PREC_F16X2: two-plane f16 operands (common.h h2_t).  The kernels see the same bytes as f16 matrices of twice the width.
+static int gemm_h2(const GemmBf16Args& a, hipStream_t s) {
+  SG_REQUIRE(!a.fp8 && !a.copy16 && !a.ln_stats && !a.rowdot && !a.row_scale && !a.col_scale && !a.a_mx && !a.c_mx,
+             "gemm_h2: the fp8 / folded-LayerNorm / row-dot forms do not exist for two-plane f16 operands");
+  SG_REQUIRE(a.K % 32 == 0, "gemm_h2: K=%d must be a multiple of 32 (pad the operands)", a.K);
+  SG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.strideA % 8 == 0 && a.strideW % 8 == 0, "gemm_h2: operand strides must be multiples of 8 elements (32-byte storage groups)");
+  SG_REQUIRE((((uintptr_t)a.A) & 31) == 0 && (((uintptr_t)a.W) & 31) == 0, "gemm_h2: operands must be 32-byte aligned");
+  SG_REQUIRE(a.act >= 0 && a.act <= 2, "gemm_h2: bad act %d", a.act);
+  bool vec = (a.N % 8 == 0) && (a.ldc % 8 == 0) && (a.strideC % 8 == 0) && ((((uintptr_t)a.C) & 31) == 0);
+  if (a.bias) vec = vec && ((((uintptr_t)a.bias) & 15) == 0);
+  if (a.residual) vec = vec && (a.ldr % 4 == 0) && ((((uintptr_t)a.residual) & 15) == 0);
+  if (a.c_is_bf16) SG_REQUIRE(vec && !a.residual, "gemm_h2: a two-plane C needs N %% 8 == 0, ldc %% 8 == 0, a 32-byte aligned C and no residual");
+  GemmBf16Args h = a;
+  h.K = a.K * 2; h.lda = a.lda * 2; h.ldw = a.ldw * 2; h.strideA = a.strideA * 2; h.strideW = a.strideW * 2; h.f16 = 1;
+  const bool big = a.M >= 1024 && a.N >= 512 && !(few_tiles(a.M, a.N) && a.batch == 1);
+  prof_begin(PROF_GEMM_H2, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
+  const int rc = big ? launch_pingpong(h, vec, s) : launch_ring<128, 128, 2, 2, 2, 0, 64, false, true, false, 0, true>(h, vec, s);
+  prof_end(PROF_GEMM_H2, s);
+  if (rc != SG_OK) return rc;
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
 int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   SG_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.h2) return gemm_h2(a, s);
   if (a.fp8) return gemm_fp8(a, s);
   SG_REQUIRE(a.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d (pad the operands)", a.K, BK);
   SG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.strideA % 8 == 0 && a.strideW % 8 == 0,

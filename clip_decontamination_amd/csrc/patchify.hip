@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(sg_tile_batch t, int P_rt
         }
       }
     }
-    out[(row0 + pxi) * Kpad + k] = from_f32<OutT>(v);
+    st_elem<OutT>(out + (row0 + pxi) * Kpad, k, v);
   }
 }
 
@@ -49,7 +49,13 @@ int patchify(const sg_tile_batch& t, int P, void* out, int Kpad, int out_bf16, h
   SG_REQUIRE(t.n_tiles < 65536, "patchify: too many tiles in one launch");
   dim3 grid((unsigned)t.grid_h, (unsigned)t.n_tiles);
   const bool std_pad = Kpad == (3 * P * P + 63) / 64 * 64;
-  if (out_bf16 == HK_F16) {
+  if (out_bf16 == HK_F16X2) {                            // two-plane f16 (Kpad % 8 == 0: row starts sit on storage-group boundaries)
+    SG_REQUIRE(Kpad % 8 == 0, "patchify: two-plane f16 rows are multiples of 8 elements");
+    if (std_pad && P == 14) hipLaunchKernelGGL((patchify_kernel<h2_t, 14>), grid, dim3(256), 0, s, t, P, (h2_t*)out, Kpad);
+    else if (std_pad && P == 16) hipLaunchKernelGGL((patchify_kernel<h2_t, 16>), grid, dim3(256), 0, s, t, P, (h2_t*)out, Kpad);
+    else hipLaunchKernelGGL((patchify_kernel<h2_t, 0>), grid, dim3(256), 0, s, t, P, (h2_t*)out, Kpad);
+  }
+  else if (out_bf16 == HK_F16) {
     if (std_pad && P == 14) hipLaunchKernelGGL((patchify_kernel<f16_t, 14>), grid, dim3(256), 0, s, t, P, (f16_t*)out, Kpad);
     else if (std_pad && P == 16) hipLaunchKernelGGL((patchify_kernel<f16_t, 16>), grid, dim3(256), 0, s, t, P, (f16_t*)out, Kpad);
     else hipLaunchKernelGGL((patchify_kernel<f16_t, 0>), grid, dim3(256), 0, s, t, P, (f16_t*)out, Kpad);

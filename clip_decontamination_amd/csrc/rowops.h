@@ -56,6 +56,7 @@ struct AttnArgs {
   bf16_t* ctx; int64_t ctx_sb, ctx_st;      // output [B,N,H*dv] bf16
   float out_scale;
   int f16;                                  // operands and ctx are IEEE f16 instead of bf16 (SG_PREC_F16)
+  int h2;                                   // SG_PREC_F16X2: operands and ctx are two-plane f16; every stride above is then in f16 UNITS (2 x the element stride)
 };
 int attention_bf16(const AttnArgs& a, hipStream_t s);
 

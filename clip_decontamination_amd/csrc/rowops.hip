@@ -8,18 +8,25 @@ namespace sg {
 
 constexpr int LN_MAX_VEC = 8;      // float4 per lane kept in registers: D <= 64 * 4 * 8 = 2048
 
+// elements e .. e+3 (e % 4 == 0) of the row starting at `row`
 template <typename OutT>
-__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+__device__ __forceinline__ void store4(OutT* row, int e, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* row, int e, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(row + e) = make_float4(a, b, c, d);
 }
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* row, int e, float a, float b, float c, float d) {
   uint2 o; o.x = pack_bf2(a, b); o.y = pack_bf2(c, d);
-  *reinterpret_cast<uint2*>(p) = o;
+  *reinterpret_cast<uint2*>(row + e) = o;
 }
-template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float a, float b, float c, float d) {
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* row, int e, float a, float b, float c, float d) {
   uint2 o; o.x = pack_h2(a, b); o.y = pack_h2(c, d);
-  *reinterpret_cast<uint2*>(p) = o;
+  *reinterpret_cast<uint2*>(row + e) = o;
+}
+template <> __device__ __forceinline__ void store4<h2_t>(h2_t* row, int e, float a, float b, float c, float d) {   // half a storage group: 8 B hi, 8 B lo
+  uint2 hi, lo;
+  split_h2(a, b, hi.x, lo.x); split_h2(c, d, hi.y, lo.y);
+  uint16_t* g = reinterpret_cast<uint16_t*>(row) + ((e >> 3) << 4) + (e & 7);
+  *reinterpret_cast<uint2*>(g) = hi; *reinterpret_cast<uint2*>(g + 8) = lo;
 }
 
 // Normalise the row held in v[] (nvec float4 per lane) -- reference LayerNorm/LayerNormFp32
@@ -47,7 +54,7 @@ __device__ __forceinline__ void ln_row(float4 (&v)[LN_MAX_VEC], int D, int lane,
     if (idx < nv) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * idx);
       const float4 b = *reinterpret_cast<const float4*>(beta + 4 * idx);
-      store4<OutT>(out + 4 * idx, (v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+      store4<OutT>(out, 4 * idx, (v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
                    (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
     }
   }
@@ -75,7 +82,10 @@ int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta
   SG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: row strides must be multiples of 4");
   if (rows == 0) return SG_OK;
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (y_is_bf16 == HK_F16) hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (f16_t*)y, ldy, rows, D, eps);
+  if (y_is_bf16 == HK_F16X2) {
+    SG_REQUIRE(D % 8 == 0 && ldy % 8 == 0, "layernorm: two-plane f16 output needs D and the row stride to be multiples of 8");
+    hipLaunchKernelGGL(layernorm_kernel<h2_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (h2_t*)y, ldy, rows, D, eps);
+  } else if (y_is_bf16 == HK_F16) hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (f16_t*)y, ldy, rows, D, eps);
   else if (y_is_bf16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, ldy, rows, D, eps);
   else hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, ldx, gamma, beta, (float*)y, ldy, rows, D, eps);
   SG_LAUNCH_CHECK();
@@ -309,10 +319,24 @@ __global__ void pack_f32_kernel(const float* __restrict__ src, int64_t rows, int
   const int64_t r = i / cols_pad; const int c = (int)(i % cols_pad);
   dst[i] = c < cols ? src[r * ld_src + c] : 0.f;
 }
+// two-plane f16: one thread per storage group (8 elements -> 32 bytes)
+__global__ void pack_h2_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld_src, h2_t* __restrict__ dst, int cols_pad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int gpr = cols_pad >> 3;
+  if (i >= rows * gpr) return;
+  const int64_t r = i / gpr; const int c0 = (int)(i % gpr) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = c0 + j < cols ? src[r * ld_src + c0 + j] : 0.f;
+  store_h2x8(dst + r * cols_pad + c0, v);
+}
 int pack_rows(const float* src, int64_t rows, int cols, int64_t ld_src, void* dst, int cols_pad, int to_bf16, hipStream_t s) {
   const int64_t total = rows * cols_pad;
   if (total == 0) return SG_OK;
-  if (to_bf16 == HK_F16) hipLaunchKernelGGL(pack_half_kernel<f16_t>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (f16_t*)dst, cols_pad);
+  if (to_bf16 == HK_F16X2) {
+    SG_REQUIRE(cols_pad % 8 == 0, "pack_rows: two-plane f16 rows are multiples of 8 elements (got %d)", cols_pad);
+    hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)cdiv(total / 8, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (h2_t*)dst, cols_pad);
+  } else if (to_bf16 == HK_F16) hipLaunchKernelGGL(pack_half_kernel<f16_t>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (f16_t*)dst, cols_pad);
   else if (to_bf16) hipLaunchKernelGGL(pack_half_kernel<bf16_t>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (bf16_t*)dst, cols_pad);
   else hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, rows, cols, ld_src, (float*)dst, cols_pad);
   SG_LAUNCH_CHECK();
@@ -379,9 +403,11 @@ __global__ void transpose_pack_kernel(const float* __restrict__ src, int rows, i
   if (i >= (int64_t)rows * cols) return;
   const int c = (int)(i / rows), r = (int)(i % rows);
   const float v = src[(int64_t)r * cols + c];
-  if (to_bf16 == HK_F16) ((f16_t*)dst)[i] = f2h(v); else if (to_bf16) ((bf16_t*)dst)[i] = f2bf(v); else ((float*)dst)[i] = v;
+  if (to_bf16 == HK_F16X2) st_elem<h2_t>((h2_t*)dst + (int64_t)c * rows, r, v);      // rows % 8 == 0 (checked on the host)
+  else if (to_bf16 == HK_F16) ((f16_t*)dst)[i] = f2h(v); else if (to_bf16) ((bf16_t*)dst)[i] = f2bf(v); else ((float*)dst)[i] = v;
 }
 int transpose_pack(const float* src, int rows, int cols, void* dst, int to_bf16, hipStream_t s) {
+  if (to_bf16 == HK_F16X2) SG_REQUIRE(rows % 8 == 0, "transpose_pack: two-plane f16 rows are multiples of 8 elements (got %d)", rows);
   hipLaunchKernelGGL(transpose_pack_kernel, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, rows, cols, dst, to_bf16);
   SG_LAUNCH_CHECK();
   return SG_OK;
@@ -398,14 +424,15 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const InT* __restrict_
   const InT* xr = x + (row / inner) * so + (row % inner) * si;
   OutT* yr = y + (row / inner) * yo + (row % inner) * yi;
   float ss = 0.f;
-  for (int i = lane; i < D; i += 64) { const float v = to_f32<InT>(xr[i]); ss += v * v; }
+  for (int i = lane; i < D; i += 64) { const float v = ld_elem<InT>(xr, i); ss += v * v; }
   const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
-  for (int i = lane; i < D; i += 64) yr[i] = from_f32<OutT>(to_f32<InT>(xr[i]) * inv);
+  for (int i = lane; i < D; i += 64) st_elem<OutT>(yr, i, ld_elem<InT>(xr, i) * inv);
 }
 template <typename InT>
 static void l2norm_launch_out(const InT* x, int64_t so, int64_t si, int inner, void* y, int y_kind, int64_t yo, int64_t yi, int64_t rows, int D,
                               float eps, dim3 grid, hipStream_t s) {
-  if (y_kind == HK_F16) hipLaunchKernelGGL((l2norm_rows_kernel<InT, f16_t>), grid, dim3(256), 0, s, x, so, si, inner, (f16_t*)y, yo, yi, rows, D, eps);
+  if (y_kind == HK_F16X2) hipLaunchKernelGGL((l2norm_rows_kernel<InT, h2_t>), grid, dim3(256), 0, s, x, so, si, inner, (h2_t*)y, yo, yi, rows, D, eps);
+  else if (y_kind == HK_F16) hipLaunchKernelGGL((l2norm_rows_kernel<InT, f16_t>), grid, dim3(256), 0, s, x, so, si, inner, (f16_t*)y, yo, yi, rows, D, eps);
   else if (y_kind == HK_BF16) hipLaunchKernelGGL((l2norm_rows_kernel<InT, bf16_t>), grid, dim3(256), 0, s, x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps);
   else hipLaunchKernelGGL((l2norm_rows_kernel<InT, float>), grid, dim3(256), 0, s, x, so, si, inner, (float*)y, yo, yi, rows, D, eps);
 }
@@ -413,7 +440,10 @@ int l2norm_rows(const void* x, int x_bf16, int64_t so, int64_t si, int inner, vo
                 int64_t rows, int D, float eps, hipStream_t s) {
   if (rows == 0) return SG_OK;
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (x_bf16 == HK_F16) l2norm_launch_out<f16_t>((const f16_t*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
+  if (x_bf16 == HK_F16X2 || y_bf16 == HK_F16X2)
+    SG_REQUIRE(so % 8 == 0 && si % 8 == 0 && yo % 8 == 0 && yi % 8 == 0, "l2norm_rows: two-plane f16 rows must start on multiples of 8 elements");
+  if (x_bf16 == HK_F16X2) l2norm_launch_out<h2_t>((const h2_t*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
+  else if (x_bf16 == HK_F16) l2norm_launch_out<f16_t>((const f16_t*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
   else if (x_bf16 == HK_BF16) l2norm_launch_out<bf16_t>((const bf16_t*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
   else l2norm_launch_out<float>((const float*)x, so, si, inner, y, y_bf16, yo, yi, rows, D, eps, grid, s);
   SG_LAUNCH_CHECK();
@@ -529,13 +559,14 @@ __global__ __launch_bounds__(256) void head_norms_kernel(const T* __restrict__ x
   const int t = (int)(row / H), hd = (int)(row % H);
   const T* p = x + (int64_t)b * sb + (int64_t)t * st + hd * dh;
   float ss = 0.f;
-  for (int i = lane; i < dh; i += 64) { const float v = to_f32<T>(p[i]); ss += v * v; }
+  for (int i = lane; i < dh; i += 64) { const float v = ld_elem<T>(p, i); ss += v * v; }
   ss = wave_sum(ss);
   if (lane == 0) out[((int64_t)b * H + hd) * N + t] = sqrtf(ss);
 }
 int head_norms(const void* x, int is_bf16, int64_t sb, int64_t st, int B, int N, int H, int dh, float* out, hipStream_t s) {
   dim3 grid((unsigned)cdiv((int64_t)N * H, 4), (unsigned)B);
-  if (is_bf16 == HK_F16) hipLaunchKernelGGL(head_norms_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, sb, st, N, H, dh, out);
+  if (is_bf16 == HK_F16X2) hipLaunchKernelGGL(head_norms_kernel<h2_t>, grid, dim3(256), 0, s, (const h2_t*)x, sb, st, N, H, dh, out);
+  else if (is_bf16 == HK_F16) hipLaunchKernelGGL(head_norms_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, sb, st, N, H, dh, out);
   else if (is_bf16) hipLaunchKernelGGL(head_norms_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, sb, st, N, H, dh, out);
   else hipLaunchKernelGGL(head_norms_kernel<float>, grid, dim3(256), 0, s, (const float*)x, sb, st, N, H, dh, out);
   SG_LAUNCH_CHECK();

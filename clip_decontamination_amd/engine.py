@@ -137,6 +137,9 @@ class HipVisionTower:
             o.selfattn_strength, o.selfattn_threshold = float(sa.enhancement_strength), float(sa.min_self_attn_threshold)
         if model_type == "GEM":
             o.ignore_residual = int(bool(self.gem_ignore_residual))
+            # GEM's replaced forward (gem_utils.py:159-199) has no hook positions: of the refiners only the outlier suppressor has a
+            # defined place in it here (BASELINE configs[2] as one forward) -- the others stay off, as in the reference
+            o.similarity_enabled = o.selfattn_enabled = o.layer_fusion_enabled = 0
         return o
 
     def _workspace(self, nbytes: int):

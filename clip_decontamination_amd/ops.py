@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F16, PREC_F32, PREC_FP8, MODEL_TYPES, check
+from ._lib import PREC_BF16, PREC_F16, PREC_F16X2, PREC_F32, PREC_FP8, MODEL_TYPES, check
 
 
 def _require_gpu(*tensors):
@@ -54,6 +54,8 @@ def precision_id(precision) -> int:
         return PREC_FP8
     if precision in (PREC_F16, "f16", "fp16", "half", torch.float16):
         return PREC_F16
+    if precision in (PREC_F16X2, "f16x2", "exact"):       # two-plane f16: f32-grade results on the f16 matrix pipe (include/segearth_hip.h)
+        return PREC_F16X2
     raise ValueError(f"unknown precision {precision!r}")
 
 
@@ -81,7 +83,7 @@ def linear(A, W, bias=None, residual=None, act: int = 0, precision="bf16"):
     N = W.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     Kp = (K + 63) // 64 * 64
-    buf = scratch((M + N) * Kp * 2 + 1024, A.device)
+    buf = scratch((M + N) * Kp * 4 + 1024, A.device)      # 4 bytes per element covers every operand form (two-plane f16 included)
     sp, sn = _aligned(buf)
     bias = None if bias is None else _f32(bias)
     residual = None if residual is None else _f32(residual)

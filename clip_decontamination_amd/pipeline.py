@@ -259,9 +259,11 @@ class SegPipeline:
                                         self.cross_tile_fusion.get("fusion_mode", "weighted"),
                                         self.cross_tile_fusion.get("fusion_strength", 0.3))
             cls = None if cls_all[0] is None else torch.cat(cls_all, 0)
-            if self.upsampler is not None:
-                raise NotImplementedError("cross-tile fusion together with the JBU upsampler is not wired")
             tok, f = self._pre_head(tok, cls)
+            if self.upsampler is not None:
+                # segmentor.py:368-372 after cross_tile_fusion.py:238-320: the FUSED tokens go through the upsampler (tokens -> fusion -> JBU -> logits)
+                return self.upsampler.logits(tok, cls, scene, win, tile_hw, (l, t), (gh, gw), self.text, f, self.cls_token_lambda, scene_index,
+                                             padded_hw=(th + t + b, tw + l + r))
             lg = ops.cosine_logits(tok, cls, self.text, f, self.cls_token_lambda if cls is not None else 0.0)
             return lg.reshape(win.shape[0], self.num_queries, gh, gw)
         for i, j in launch_chunks(win.shape[0], self.tiles_per_launch):
@@ -315,8 +317,11 @@ class SegPipeline:
         """Tiles partitioned over the ranks of ``group`` -> this rank's band of the stitched canvas: (band [Q, rows, W], first row,
         band boundaries of all ranks).  Patch-grid logits (44 kB per tile) are rebuilt everywhere with ONE all-gather (RCCL over xGMI);
         per-pixel logits (upsampler: 16-32 MB per tile) travel point to point, only the tiles that straddle a band edge.  Either way each
-        rank stitches ONLY its own band, so the tail scales with the ranks too; the band equals the same rows of the single-process
-        canvas bit for bit (the write-once stitch averages the covering tiles in raster order, and all of them are present)."""
+        rank stitches ONLY its own band, so the tail scales with the ranks too.  The stitch itself is identical given identical tile
+        logits (write-once: the covering tiles are averaged in raster order, and all of them are present); the tile logits of a rank
+        equal the single process's bit for bit in parity mode (f32: tests/test_gpu_distributed.py), while the 2-byte modes may take a
+        different kernel path for a different launch size (few tiles per launch: 128 x 128 GEMM tiles and a separate LayerNorm pass,
+        DESIGN.md section 4), i.e. differ by 2-byte rounding (bounded in the same test file)."""
         H, W, stride, crop, wins, tile_hw, pad_tl, up_hw, grid = self._geometry(scene, stride, crop)
         world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
         check_same_scene([H, W, len(wins), crop[0], crop[1], stride[0], stride[1], self.num_queries], self.device, group)
@@ -324,13 +329,16 @@ class SegPipeline:
         lo, hi = partition(T, world, rank)
         plan = band_plan(wins, H, world)
         yb, need = plan
-        if self.upsampler is None or self.cross_tile_fusion is not None:
+        if self.upsampler is None:
             tl = self.gather_tile_logits(scene, wins, tile_hw, world, rank, group, grid_of_tiles=grid)
             a, b = need[rank]
             tiles, first = tl[a:b], a
         else:
             mine = list(wins[lo:hi])
-            local = self.tile_logits(scene, mine if mine else [wins[0]], tile_hw)[:hi - lo]
+            if self.cross_tile_fusion is not None and T > 1:      # strips are exchanged first (two small all-gathers), then JBU on the fused tokens
+                local = self._fused_tile_logits(scene, mine if mine else [wins[0]], tile_hw, grid, T, world, rank, group, n_real=hi - lo)
+            else:
+                local = self.tile_logits(scene, mine if mine else [wins[0]], tile_hw)[:hi - lo]
             tiles, first = exchange_halo_tiles(local, wins, world, rank, group, plan)
         y0, y1 = yb[rank], yb[rank + 1]
         if y1 <= y0:
@@ -390,8 +398,6 @@ class SegPipeline:
         P = v.cfg.patch
         l, r, t, b = compute_padsize(tile_hw[0], tile_hw[1], P)
         gh, gw = (tile_hw[0] + t + b) // P, (tile_hw[1] + l + r) // P
-        if self.upsampler is not None:
-            raise NotImplementedError("cross-tile fusion together with the JBU upsampler is not wired")
         opts = v.forward_opts(self.model_type, self.ignore_residual, self.apply_similarity_enhancement,
                               getattr(self, "apply_layer_fusion", False), getattr(self, "layer_fusion_lambda", 0.5))
         win = torch.tensor(list(mine), dtype=torch.int32, device=self.device).reshape(-1, 4)
@@ -406,8 +412,11 @@ class SegPipeline:
                                    cf.get("fusion_strength", 0.3), grid_of_tiles[1])
         tok = sharded_cross_tile_fusion(tok, steps, T, world, rank, group)
         if n_real == 0:
-            return tok.new_zeros((0, self.num_queries, gh, gw))
+            return tok.new_zeros((0, self.num_queries) + ((16 * gh, 16 * gw) if self.upsampler is not None else (gh, gw)))
         tok, f = self._pre_head(tok, cls)
+        if self.upsampler is not None:                   # fused tokens -> JBU -> per-pixel logits of this rank's tiles (they travel as halo tiles)
+            return self.upsampler.logits(tok, cls, scene, win[:n_real], tile_hw, (l, t), (gh, gw), self.text, f, self.cls_token_lambda, None,
+                                         padded_hw=(tile_hw[0] + t + b, tile_hw[1] + l + r))
         lg = ops.cosine_logits(tok, cls, self.text, f, self.cls_token_lambda if cls is not None else 0.0)
         return lg.reshape(n_real, self.num_queries, gh, gw)
 

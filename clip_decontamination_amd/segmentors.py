@@ -375,7 +375,7 @@ class Segmentor(_HipSegmentorBase):
                  logit_scale=50, slide_stride=112, slide_crop=224, cls_token_lambda=0, bg_idx=0, apply_sim_feat_up=True,
                  sim_feat_up_cfg=dict(model_name="jbu_one", model_path="your/model/path"),
                  checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
-                 tokenizer=None, cross_tile_fusion_cfg=None, tile_group=None):
+                 tokenizer=None, cross_tile_fusion_cfg=None, tile_group=None, apply_outlier_suppression=False, outlier_suppression_cfg=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
         if model_type == "GEM" and cls_token_lambda != 0:
@@ -388,3 +388,12 @@ class Segmentor(_HipSegmentorBase):
         self.cross_tile_fusion_cfg = cross_tile_fusion_cfg
         self.output_cls_token = cls_token_lambda != 0
         self.apply_similarity_enhancement = False
+        # opt-in extra (BASELINE configs[2]: "GEM self-self attn + outlier_suppression" in ONE forward).  The reference cannot run that
+        # composition (SegmentorEx crashes on GEM and this class has no refiners); the definition built here -- detection on the
+        # ordinary stream's attention of block L-2, suppression on the GEM stream before ln_post -- is written down in DESIGN.md section 7 and
+        # restated in oracle/vit.py::gem_forward.  Same kwargs as SegmentorEx (segmentor.py:251-274).
+        self.apply_outlier_suppression = _to_bool(apply_outlier_suppression)
+        if self.apply_outlier_suppression:
+            c = dict(top_k=10)
+            c.update(outlier_suppression_cfg or {})
+            self.net.visual.outlier_suppressor = OutlierSuppressionModule(top_k=c["top_k"])

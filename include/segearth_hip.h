@@ -46,6 +46,12 @@ enum sg_precision {       /* arithmetic the ViT GEMMs / attention run in */
   SG_PREC_F16 = 3,        /* throughput mode on IEEE f16 operands (v_mfma_*_f16: the bf16 rate, 3 more mantissa bits): the reference's own
                              GPU arithmetic (segmentor.py:467 .half(), open_clip/model.py:142 fp32 LayerNorm).  f32 accumulate, f32
                              residual stream / LN / softmax statistics as in bf16 mode; stores saturate at +-65504 */
+  SG_PREC_F16X2 = 4,      /* parity AT SPEED: every GEMM / attention operand is held as two f16 planes x = hi + lo (22 significant bits) and every
+                             product is issued as hi.hi + hi.lo + lo.hi on the f16 matrix pipe into one f32 accumulator -- the error of an f32
+                             fmaf chain (tools/h2_probe.hip) at a third of the f16 MFMA rate instead of the 1/16 of the f32 MFMA.  f32 residual
+                             stream / LayerNorm / softmax statistics, exact expf / erff activations.  Logits within 1e-3 of the reference's fp32 CPU
+                             path with arg-max identical up to fp32 ties, like SG_PREC_F32 (same reference bar: segmentor.py:467 .half() is the
+                             reference's own GPU arithmetic; its CPU path, the oracle, is fp32).  Values beyond +-131008 are not representable. */
 };
 
 /* last-block attention variants: reference open_clip/transformer.py:858-932 (custom_attn),

@@ -63,7 +63,8 @@ class SegOracle:
     def forward_feature(self, img, logit_size=None):
         P = self.cfg.patch
         if self.model_type == "GEM":
-            feats = vit_oracle.gem_forward(self.weights, self.cfg, img, self.ignore_residual, self.gem_depth)
+            feats = vit_oracle.gem_forward(self.weights, self.cfg, img, self.ignore_residual, self.gem_depth,
+                                           outlier_cfg=self.outlier_cfg)       # composition of BASELINE configs[2], defined in gem_forward
             cls = None
         else:
             cls, feats = vit_oracle.vit_forward(

@@ -259,13 +259,17 @@ def vit_forward(w: W, cfg, img, model_type: str = "SegEarth", ignore_residual: b
 # GEM (gem/gem_utils.py, gem/gem_wrapper.py)
 # --------------------------------------------------------------------------------------------
 
-def gem_block(w: W, cfg, i: int, x_gem, x, ignore_residual: bool):
-    """gem/gem_utils.py:60-123,132-153 with ss_attn_iter=1, ss_attn_temp=None."""
+def gem_block(w: W, cfg, i: int, x_gem, x, ignore_residual: bool, capture: Optional[dict] = None):
+    """gem/gem_utils.py:60-123,132-153 with ss_attn_iter=1, ss_attn_temp=None.  ``capture`` (composition only, see gem_forward)
+    receives the head-averaged attention [B,N,N] of the ORDINARY stream of this block."""
     p = f"transformer.resblocks.{i}."
     H, scale = cfg.heads, cfg.head_dim ** -0.5
     xn = layer_norm(x, w, p + "ln_1")
     q, k, v = qkv_proj(w, p, xn, H)
-    ori = out_proj(w, p, torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v)
+    a_ori = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1)
+    if capture is not None:
+        capture["attn"] = a_ori.mean(dim=1)                    # what nn.MultiheadAttention(need_weights=True) hands back
+    ori = out_proj(w, p, a_ori @ v)
     inv_temp = (xn.norm(dim=-1).mean(dim=-1) * scale).view(-1, 1, 1, 1)   # per image (:79-81)
 
     def stream(t):
@@ -281,15 +285,34 @@ def gem_block(w: W, cfg, i: int, x_gem, x, ignore_residual: bool):
     return x_gem, x_ori
 
 
-def gem_forward(w: W, cfg, img, ignore_residual: bool = True, depth: int = 7):
-    """gem/gem_utils.py:159-199: tokens [B,n,E] of the GEM stream (no CLS, R5)."""
+def gem_forward(w: W, cfg, img, ignore_residual: bool = True, depth: int = 7, outlier_cfg: Optional[dict] = None):
+    """gem/gem_utils.py:159-199: tokens [B,n,E] of the GEM stream (no CLS, R5).
+
+    ``outlier_cfg`` -- BASELINE configs[2] names "GEM self-self attn + outlier_suppression" as ONE forward.  The reference cannot run it
+    (SegmentorEx crashes on GEM, R5; GEM's replaced forward ignores the suppressor), so this is a DEFINED composition of two stages that
+    are each pinned to the reference (parity of the composition itself is unpinned):
+      * detection reads what the ordinary forward reads (transformer.py:609-610): the head-averaged attention of block L-2 -- here the
+        ORDINARY ("ori") stream of that block, the only stream that runs nn.MultiheadAttention's q k^T attention;
+      * suppression acts where the ordinary forward applies it (transformer.py:721-742): on the patch tokens of the final feature map
+        before ln_post -- here the GEM stream x_gem -- through the unchanged OutlierSuppressionModule (outlier_suppression.py:83-214)."""
     L = cfg.layers
     x, gh, gw = embed(w, cfg, img, gem=True)
     first = L - (depth - 1)
+    attn = None
     for i in range(first):
-        x, _ = res_block(w, cfg, i, x)
+        x, a = res_block(w, cfg, i, x, need_weights=outlier_cfg is not None and i == L - 2)
+        attn = a if a is not None else attn
     x_gem = x
     for i in range(first, L):
-        x_gem, x = gem_block(w, cfg, i, x_gem, x, ignore_residual)
+        cap = {} if (outlier_cfg is not None and i == L - 2) else None
+        x_gem, x = gem_block(w, cfg, i, x_gem, x, ignore_residual, cap)
+        if cap is not None:
+            attn = cap["attn"]
+    if outlier_cfg is not None and attn is not None:
+        B, N, D = x_gem.shape
+        grid = x_gem[:, 1:].permute(0, 2, 1).reshape(B, D, gh, gw)
+        idx = refine.detect_outliers(attn, gh * gw, outlier_cfg.get("top_k", 10))
+        grid = refine.suppress_outliers(grid, idx, outlier_cfg.get("contamination_temp", 0.1))
+        x_gem = torch.cat([x_gem[:, :1], grid.reshape(B, D, gh * gw).permute(0, 2, 1)], 1)
     y = layer_norm(x_gem, w, "ln_post") @ w["proj"]
     return y[:, 1:]

@@ -33,7 +33,7 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(197, 192, 192), (64, 64, 64), (130, 260, 588), (2740, 3072, 1024), (1370, 1024, 4096), (33, 7, 50)])
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 3e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x2", 2e-5), ("bf16", 2e-2), ("f16", 3e-3)])
 def test_linear(ops, M, N, K, prec, tol):
     A, W, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
     for act in (0, 1, 2):
@@ -58,6 +58,8 @@ def test_linear_identity_asymmetric(ops):
     out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="f16")
     assert rel_err(out, W.T.half().float()) < 1e-6
     out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="f32")
+    assert rel_err(out, W.T) < 1e-6
+    out = ops.linear(torch.eye(n).to(DEV), W.to(DEV), precision="f16x2")          # two planes: 22 significant bits of W survive
     assert rel_err(out, W.T) < 1e-6
 
 
@@ -115,7 +117,7 @@ SHAPES = [(2, 37, 64, 2), (1, 197, 128, 2), (1, 300, 160, 2), (1, 1370, 128, 2),
 
 @pytest.mark.parametrize("B,N,D,H", SHAPES)
 @pytest.mark.parametrize("variant", ["vanilla", "ClearCLIP", "SCLIP", "SegEarth", "SFP", "Experimental"])
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x2", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
 def test_attention(ops, B, N, D, H, variant, prec, tol):
     qkv = rnd(B, N, 3 * D, seed=N + D, scale=1.0)
     sim = None
@@ -128,7 +130,7 @@ def test_attention(ops, B, N, D, H, variant, prec, tol):
 
 
 @pytest.mark.parametrize("variant", ["NACLIP", "NOnly", "GAV"])
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x2", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
 def test_attention_gaussian_window(ops, variant, prec, tol):
     """NACLIP / NOnly / GAV (reference open_clip/transformer.py:909-932): Gaussian neighbourhood bias, square grids."""
     for (B, g, D, H) in ((2, 6, 64, 2), (1, 14, 128, 2), (1, 37, 128, 2)):
@@ -139,7 +141,7 @@ def test_attention_gaussian_window(ops, variant, prec, tol):
         assert rel_err(out, ref) < tol, (variant, g, rel_err(out, ref))
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16", 3e-2), ("f16", 4e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("f16x2", 1e-5), ("bf16", 3e-2), ("f16", 4e-3)])
 def test_attention_stats(ops, prec, tol):
     B, N, D, H = 2, 101, 128, 2
     qkv = rnd(B, N, 3 * D, seed=3)
@@ -151,7 +153,7 @@ def test_attention_stats(ops, prec, tol):
     assert rel_err(a_diag, torch.diagonal(am, dim1=-2, dim2=-1)) < tol
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("bf16", 1e-2), ("f16", 1.5e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("f16x2", 2e-6), ("bf16", 1e-2), ("f16", 1.5e-3)])
 def test_similarity_map(ops, golden, prec, tol):
     g = golden("refine")
     f = torch.from_numpy(g["sim_feats"])
@@ -378,6 +380,35 @@ def test_jbu_fused_logits_tail_equals_unfused_and_oracle(golden, ops, use_cls):
     assert d_fu < 2e-3 and d_or < 3e-3
 
 
+def test_jbu_fused_tail_feature_dim_not_a_multiple_of_256(ops):
+    """C = 640 (64 | C, 256 does not divide C): the row-dot epilogue of the persistent GEMM must not write slice sums for the columns past C
+    (the waves of the last 256-wide tile that own no 64-column slice), and a C = 512 upsampler run first must not pin the pixel-logits
+    kernel's dynamic-LDS limit at the smaller size.  Fused tail against the unfused bf16 path."""
+    import ctypes as C
+    from clip_decontamination_amd import _lib, weights as Wt
+    from clip_decontamination_amd.upsampler import get_upsampler
+    from clip_decontamination_amd.ops import ptr, stream_ptr
+    lib = _lib.load()
+    for Cdim in (512, 640):
+        up = get_upsampler("jbu_stack", Cdim, DEV, "bf16")
+        up.load_state_dict(Wt.make_jbu_weights("jbu_stack", Cdim, seed=3))
+        B, Q, gs = 1, 9, 4
+        tok = rnd(B, gs * gs, Cdim, seed=11).to(DEV)
+        guid = (torch.nn.functional.interpolate(rnd(B, 3, 6, 6, seed=12), size=(16 * gs, 16 * gs), mode="bicubic") + 0.1 * rnd(B, 3, 16 * gs, 16 * gs, seed=13)).to(DEV)
+        text = torch.nn.functional.normalize(rnd(Q, Cdim, seed=14), dim=-1).to(DEV)
+        feats = up.upsample_tokens(tok, guid, gs, gs)
+        unfused = ops.cosine_logits(feats, None, text, 0.0, 0.0)
+        P = 256 * gs * gs
+        fused = torch.empty(B, Q, P, dtype=torch.float32, device=DEV)
+        need = lib.sg_jbu_workspace_bytes(up._ctx, B, gs, gs)
+        wp, wn = up._workspace(need)
+        _lib.check(lib.sg_jbu_logits(up._ctx, ptr(tok), ptr(guid.contiguous()), B, gs, gs, 16 * gs, 16 * gs, _lib.PREC_BF16, ptr(text.contiguous()), Q, None, 0.0,
+                                     ptr(fused), wp, wn, stream_ptr()), "sg_jbu_logits")
+        d = (fused - unfused).abs().max().item()
+        print(f"fused JBU tail C={Cdim}: |fused - unfused| = {d:.3e}")
+        assert d < 2e-3, (Cdim, d)
+
+
 def test_jbu_against_oracle_nonsquare_and_batched():
     from clip_decontamination_amd import weights as Wt
     from clip_decontamination_amd.upsampler import get_upsampler
@@ -521,9 +552,11 @@ def _ln_chain_ref(A, W1, b1, x, g, be, W2, b2, act):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
-@pytest.mark.parametrize("M,K1,D,N2,act,mean_shift", [(1370, 1024, 1024, 3072, 0, 0.0), (2055, 4096, 1024, 4096, 1, 0.0),
-                                                      (1200, 768, 768, 3072, 2, 3.0), (1024, 512, 512, 512, 0, -1.0)])
-def test_ln_chain_folded_matches_unfolded_and_f64(prec, M, K1, D, N2, act, mean_shift):
+@pytest.mark.parametrize("M,K1,D,N2,act,mean_shift,outlier", [(1370, 1024, 1024, 3072, 0, 0.0, 20.0), (2055, 4096, 1024, 4096, 1, 0.0, 20.0),
+                                                              (1200, 768, 768, 3072, 2, 3.0, 20.0), (1024, 512, 512, 512, 0, -1.0, 20.0),
+                                                              (1100, 512, 576, 640, 1, 0.5, 20.0),     # D, N2 multiples of 64 but not of the 256-wide tile
+                                                              (1370, 1024, 1024, 3072, 0, 10.0, 300.0)])  # massive-activation channel (>= 100 sigma for most rows) + row means of 1..100 sigma
+def test_ln_chain_folded_matches_unfolded_and_f64(prec, M, K1, D, N2, act, mean_shift, outlier):
     """Residual GEMM -> LayerNorm -> GEMM with the LayerNorm folded into the two epilogues: the f32 residual stream must equal the unfolded
     path's bit for bit (same GEMM), y must be as close to the f64 result as the unfolded path's (2-byte operands either way) -- also when
     the rows have a mean several standard deviations away from 0 (the case the centred statistics and the exact mean * c cancellation are for)."""
@@ -531,7 +564,7 @@ def test_ln_chain_folded_matches_unfolded_and_f64(prec, M, K1, D, N2, act, mean_
     g = lambda *sh, seed, sc=1.0: (torch.from_numpy(np.random.default_rng(seed).standard_normal(sh).astype(np.float32)) * sc).to(DEV)
     A, W1, b1 = g(M, K1, seed=1), g(D, K1, seed=2, sc=K1 ** -0.5), g(D, seed=3, sc=0.1)
     x = g(M, D, seed=4) * torch.logspace(-1, 1, M, device=DEV).view(M, 1) + mean_shift
-    x[:, 7] += 20.0                                            # one outlier channel, as real residual streams have
+    x[:, 7] += outlier                                         # one outlier channel, as real residual streams have
     gamma, beta = 1.0 + 0.3 * g(D, seed=5), 0.2 * g(D, seed=6)
     W2, b2 = g(N2, D, seed=7, sc=D ** -0.5), g(N2, seed=8, sc=0.1)
     xf, yf = ops.ln_chain(A, W1, b1, x, gamma, beta, W2, b2, act, prec, fold=True)

@@ -43,7 +43,7 @@ def test_text_golden_bf16(golden, name, prec, bound):
     assert cos.min().item() > bound, cos
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", None), ("f16", None)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("f16x2", 2e-4), ("bf16", None), ("f16", None)])
 def test_text_real_shape_vs_oracle(prec, tol):
     """ViT-B/16's text tower (512 wide, 12 layers, 77 tokens, 49408 ids) on 24 tokenizer-shaped rows."""
     tc, tt = tower("ViT-B-16", prec)

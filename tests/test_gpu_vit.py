@@ -44,9 +44,11 @@ def maxdiff(a, b):
     return (torch.as_tensor(a).float().cpu() - torch.as_tensor(b).float().cpu()).abs().max().item()
 
 
-@pytest.fixture(scope="module")
-def tiny_f32():
-    return tower("tiny-8", "f32")
+@pytest.fixture(scope="module", params=["f32", "f16x2"])
+def tiny_f32(request):
+    """The tiny tower in an EXACT mode: f32 MFMA parity mode, or the two-plane f16 mode (SG_PREC_F16X2: f32-grade results on the f16 matrix
+    pipe) -- every test below holds both to the same fp32 bounds against the reference fixtures."""
+    return tower("tiny-8", request.param)
 
 
 @pytest.fixture(scope="module", params=["bf16", "f16"])
@@ -119,7 +121,7 @@ def test_tiny_refiners_f32(golden, tiny_f32, tag, mt):
     assert maxdiff(cls, g[f"{tag}.{mt}.cls"]) < 1e-4
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", None), ("f16", None)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x2", 1e-4), ("bf16", None), ("f16", None)])
 def test_tiny_gem(golden, prec, tol):
     cfg, net = tower("tiny-gem", prec)
     g = golden("vit_tiny-gem")
@@ -141,11 +143,12 @@ def head_logits(net, cfg, img, mt, text, precision_tag):
     return lg.reshape(1, -1, g, g)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
 @pytest.mark.parametrize("vit,S", [("ViT-B-16", 224), ("ViT-B-16", 512), ("ViT-L-14", 224), ("ViT-L-14", 512)])
-def test_real_size_parity_f32(golden, vit, S):
+def test_real_size_parity_f32(golden, vit, S, prec):
     """BASELINE configs[0] (B/16, one 224 tile, 8 queries / 6 classes) and the L/14 512-tile shape:
-    logits within 1e-3 of the reference fixture, arg-max bit-exact."""
-    cfg, net = tower(vit, "f32")
+    logits within 1e-3 of the reference fixture, arg-max bit-exact -- in parity mode and in the two-plane f16 mode."""
+    cfg, net = tower(vit, prec)
     install(net, SIM, dict(top_k=30))
     g = golden("real_logits")
     text = torch.from_numpy(Wt.make_text_features(8, cfg.embed_dim)).to(DEV)
@@ -153,11 +156,11 @@ def test_real_size_parity_f32(golden, vit, S):
     pad = OS.compute_padsize(S, S, cfg.patch)
     imgp = (F.pad(img, pad) if any(pad) else img).to(DEV)
     for mt in ("SegEarth", "Experimental"):
-        lg = head_logits(net, cfg, imgp, mt, text, "f32")[0]
+        lg = head_logits(net, cfg, imgp, mt, text, prec)[0]
         ref = torch.from_numpy(g[f"{vit}.{S}.{mt}.logits"])
         err = maxdiff(lg, ref)
         agree = (lg.argmax(0).cpu().to(torch.uint8) == torch.from_numpy(g[f"{vit}.{S}.{mt}.argmax"])).float().mean().item()
-        print(f"[f32] {vit}@{S} {mt}: max|dlogit| = {err:.2e}, argmax agreement = {agree:.4f}")
+        print(f"[{prec}] {vit}@{S} {mt}: max|dlogit| = {err:.2e}, argmax agreement = {agree:.4f}")
         assert err < 1e-3
         assert agree == 1.0
 
@@ -234,9 +237,10 @@ def test_tiny_selfattn_attention_mode_bf16(golden, tiny_bf16, mt):
 # ---- attention-map layer fusion (apply_layer_fusion, reference transformer.py:598-607,630-637,647-690) -----------------------------
 @pytest.mark.parametrize("tag,sim,lam,ign", [("lf", None, 0.5, True), ("lf_sim", SIM, 0.3, True), ("lf_res", None, 0.5, False)])
 @pytest.mark.parametrize("mt", ["SegEarth", "Experimental"])
-def test_layer_fusion_one_head_reference_fixture_f32(golden, tag, sim, lam, ign, mt):
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
+def test_layer_fusion_one_head_reference_fixture_f32(golden, tag, sim, lam, ign, mt, prec):
     """The one configuration the reference's own layer-fusion code runs in (heads == 1): fixture from the reference."""
-    cfg, net = tower("tiny-1h", "f32")
+    cfg, net = tower("tiny-1h", prec)
     install(net, sim, dict(top_k=5))
     g = golden("vit_tiny-1h")
     cls, tok = net.encode_image(torch.from_numpy(g["img"]).to(DEV), mt, ign, output_cls_token=True, apply_layer_fusion=True,
@@ -244,7 +248,7 @@ def test_layer_fusion_one_head_reference_fixture_f32(golden, tag, sim, lam, ign,
     assert maxdiff(tok, g[f"{tag}.{mt}.tokens"]) < 1e-4 and maxdiff(cls, g[f"{tag}.{mt}.cls"]) < 1e-4
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16x2", "bf16", "f16"])
 def test_layer_fusion_multi_head_vs_oracle(prec):
     """heads > 1: the definition the one-head case pins (per-image head-averaged maps, as nn.MultiheadAttention returns them), against the
     oracle restatement; and fusion without a suppressor leaves the output unchanged."""
@@ -259,7 +263,7 @@ def test_layer_fusion_multi_head_vs_oracle(prec):
             rc, rt = OV.vit_forward(w, cfg, img, mt, True, similarity_cfg=sim, outlier_cfg=dict(top_k=5), layer_fusion={"lambda": 0.4})
         rel = maxdiff(tok, rt) / rt.abs().max().item()
         print(f"[{prec}] layer fusion {mt}: max rel token error {rel:.3e}")
-        assert rel < {"f32": 1e-5, "bf16": 0.02, "f16": 3e-3}[prec]
+        assert rel < {"f32": 1e-5, "f16x2": 1e-5, "bf16": 0.02, "f16": 3e-3}[prec]
     install(net)
     a = net.encode_image(img.to(DEV), "SegEarth", True, output_cls_token=True, apply_layer_fusion=True)[1]
     b = net.encode_image(img.to(DEV), "SegEarth", True, output_cls_token=True)[1]
