@@ -857,9 +857,11 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 // MODE 1 = the consumer side of a folded LayerNorm (2-byte output only), MODE 2 = the producer side (f32 output + 2-byte copy + slice
 // statistics): their own instantiations, so that the per-row / per-column factors of the one, the statistics of the other and the plain
 // form's deeper residual pipeline never hold registers at the same time.
-template <int MI, int NI, bool F16, int MODE = 0, int SPEC = 0>
+// SPLIT (two-plane f16, MODE 0 / SPEC 0 only): a "2-byte" C is written as [8 hi | 8 lo] storage groups; exact activations.
+template <int MI, int NI, bool F16, int MODE = 0, int SPEC = 0, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act_rt, int c_bf16_rt, int z, int row0,
                                                 int col0, float* patch, int lane) {
+  static_assert(!SPLIT || (MODE == 0 && SPEC != 5), "two-plane f16: plain epilogues only (no folded LayerNorm, no row-dot form)");
   constexpr bool LN = MODE == 1, PROD = MODE == 2;
   // SPEC > 0: activation (SPEC - 1), output type (2-byte in MODE 0 / 1, f32 in MODE 2) and the presence of a residual (MODE 2 only) are
   // compile-time constants -- straight-line strips without the run-time branches (measured on the QKV shape: -3.3 %; overlapping the
@@ -934,10 +936,10 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       }
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? quick_gelu_exact(v[e]) : quick_gelu(v[e]);
       } else if (act == ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = erf_gelu_fast(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? erf_gelu(v[e]) : erf_gelu_fast(v[e]);
       }
       v4[j] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -960,8 +962,13 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
         if (r < 8 && m < a.M && n < a.N) {
           const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + pofs);
           const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4 + pofs);
+          if constexpr (SPLIT) {
+            const float v8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            store_h2x8(reinterpret_cast<h2_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n, v8);
+          } else {
           uint4 o; o.x = pack_half2<F16>(x0.x, x0.y); o.y = pack_half2<F16>(x0.z, x0.w); o.z = pack_half2<F16>(x1.x, x1.y); o.w = pack_half2<F16>(x1.z, x1.w);
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
+          }
         }
       } else {
         constexpr int LPR = TN / 4;
@@ -1448,6 +1455,190 @@ static int launch_fp8_persist(const GemmBf16Args& a, hipStream_t s) {
   return SG_OK;
 }
 
+
+// ---- persistent two-plane f16 ping-pong (SG_PREC_F16X2: every large ViT linear of the exact mode) ------------------------------------------
+// gemm_fp8_persist's structure on two-plane f16 operands: a K step is again 128 bytes per row -- 32 elements as four [8 hi | 8 lo] storage
+// groups -- so the rings (A: 2 slots, W: 3 slots = all 160 KiB of LDS), the two MFMA phases per K step, the hand-off rules and the tile
+// switch are those of the fp8 kernel, comment for comment.  What differs:
+//   * the source-side chunk permutation also DE-INTERLEAVES the planes (as in gemm_bf16_ring<SPLIT>): LDS chunks 0-3 of a row hold the four
+//     hi chunks, 4-7 the four lo chunks, so fragment h[0] (chunk g) is the hi plane and h[1] (chunk 4 + g) the lo plane of the lane's 8 K values;
+//   * a 16 x 16 output takes THREE v_mfma_f32_16x16x32_f16 per K step (W_hi.A_hi + W_lo.A_hi + W_hi.A_lo): 48 MFMAs = 768 cycles per phase
+//     against the same READ segments as the fp8 kernel (16 / 8 ds_read_b128 + 4 LDS-DMA pieces) -- the matrix pipe has 1.5x the cover;
+//   * operand rows are 4 bytes per element (the fc output of a 128-tile launch is 2.9 GB), so a tile keeps a 64-bit base per operand and
+//     32-bit offsets inside its 256 rows;
+//   * the epilogue is epilogue_store8<.., SPLIT>: bias / exact activation / f32 residual / f32 or two-plane output, no scales.
+// `a` arrives as gemm_h2 prepared it: K, lda, ldw in f16 UNITS (2 x the element counts), C / residual strides in elements.
+// SPEC as epilogue_store8's: 0 = every choice at run time, 1 / 2 / 3 = two-plane output after no activation / QuickGELU / GELU (QKV, fc),
+// 4 = f32 output + f32 residual (out-proj, proj).
+template <int SPEC>
+__global__ __launch_bounds__(512) void gemm_h2_persist(GemmBf16Args a, int act, int c_bf16) {
+  constexpr int PBM = 256, PBN = 256, KB = 128;                          // K step in bytes
+  constexpr int SLOT = 256 * KB;                                         // 32 KiB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ldsA = lds;                                                      // 2 slots
+  char* ldsW = lds + 2 * SLOT;                                           // 3 slots
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wi = wave & 3;
+  const int tiles_n = (a.N + PBN - 1) / PBN, tiles_m = (a.M + PBM - 1) / PBM;
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const char* A = reinterpret_cast<const char*>(a.A);
+  const char* W = reinterpret_cast<const char*>(a.W);
+  const int64_t lda_b = a.lda * 2, ldw_b = a.ldw * 2;                    // row strides in bytes
+  const int nt = a.K * 2 / KB;
+  const int my_tiles = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nt;                                       // length of this workgroup's K-step stream
+
+  const int srow = lane >> 3, cpos = lane & 7;
+  // plane-de-interleaving swizzle: LDS chunk cpos of row r holds logical chunk L = cpos ^ ((r >> 1) & 7) = 4 * plane + group, which lives at
+  // global chunk 2 * group + plane.  Pieces are 8 rows apart, so the swizzle term depends on the lane and on the parity of the piece only.
+  auto gchunk = [](int L) { return ((L & 3) << 1) | (L >> 2); };
+  const int swz_e = gchunk(cpos ^ (srow >> 1)) << 4, swz_o = gchunk(cpos ^ (4 + (srow >> 1))) << 4;
+  struct Src { const char* Ab; const char* Wb; int m0, n0; };            // 64-bit tile bases (wave-uniform)
+  const int ra0 = 128 * g + 32 * wi + srow, rw0 = 64 * wi + 32 * g + srow;   // this lane's first piece row inside any tile
+  auto make_src = [&](int j) {
+    Src sp;
+    const int v = (int)blockIdx.x + j * (int)gridDim.x;                  // XCD x = v & 7 walks a contiguous chunk of tile ids
+    const int xcd = v & 7, seq = v >> 3;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+    tile = tile < nwg ? tile : nwg - 1;
+    sp.m0 = (tile / tiles_n) * PBM; sp.n0 = (tile % tiles_n) * PBN;
+    sp.Ab = A + (int64_t)sp.m0 * lda_b; sp.Wb = W + (int64_t)sp.n0 * ldw_b;
+    return sp;
+  };
+  Src cur = make_src(0);
+  Src nxt = make_src(my_tiles > 1 ? 1 : 0);
+  int cur_end = nt;                                                      // stream index where `nxt` begins
+  const int lda_i = (int)lda_b, ldw_i = (int)ldw_b;                      // < 2^23 (checked on the host): offsets inside a 256-row tile fit 32 bits
+  auto load_a = [&](int u) {                                             // this wave's pieces of A_g(u)
+    if (u >= total) return;
+    const bool nx = u >= cur_end;
+    const Src& sp = nx ? nxt : cur;
+    const int kt = nx ? u - cur_end : u - (cur_end - nt);
+    const int rmax = a.M - 1 - sp.m0;                                    // rows past the edge re-read the last row (never stored)
+    char* base = ldsA + (u & 1) * SLOT + (128 * g + 32 * wi) * KB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int r = ra0 + 8 * p; r = r < rmax ? r : rmax;
+      const int off = r * lda_i + ((p & 1) ? swz_o : swz_e) + kt * KB;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sp.Ab + off), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+    }
+  };
+  auto load_w = [&](int u) {                                             // this wave's rows of W(u)
+    if (u >= total) return;
+    const bool nx = u >= cur_end;
+    const Src& sp = nx ? nxt : cur;
+    const int kt = nx ? u - cur_end : u - (cur_end - nt);
+    const int rmax = a.N - 1 - sp.n0;
+    char* base = ldsW + (u % 3) * SLOT + (64 * wi + 32 * g) * KB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int r = rw0 + 8 * p; r = r < rmax ? r : rmax;
+      const int off = r * ldw_i + ((p & 1) ? swz_o : swz_e) + kt * KB;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sp.Wb + off), (lds_ptr_t)(base + p * 8 * KB), 16, 0, 0);
+    }
+  };
+#define SG_H2_SYNC()                                 \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    __builtin_amdgcn_s_barrier();                    \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+
+  // prologue: A(0), W(0), W(1) from everybody, W(2) from group 1 (group 0 issues its rows of W(2) in READ1(0))
+  load_a(0); load_w(0); load_w(1);
+  if (g == 1) { load_w(2); if (2 < total) wait_vmcnt<8>(); else if (1 < total) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+  else { if (1 < total) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+  SG_H2_SYNC();
+  if (g == 1) SG_H2_SYNC();
+
+  f32x4 acc[8][4];
+  bf16x8 fah[4], fal[4], fwh[4], fwl[4];                                 // hi / lo planes of the lane's 8 K values
+  int s = 0;
+  for (int j = 0; j < my_tiles; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nt; ++kt, ++s) {
+      const char* tA = ldsA + (s & 1) * SLOT;
+      const char* tW = ldsW + (s % 3) * SLOT;
+      // READ0(s): W fragments (kept for both phases) + A rows 0-63 of the group's half; issue A_g(s+1)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        fwh[jj] = read_frag(tW, 64 * wi + 16 * jj + (lane & 15), lane >> 4);
+        fwl[jj] = read_frag(tW, 64 * wi + 16 * jj + (lane & 15), 4 + (lane >> 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fah[i] = read_frag(tA, 128 * g + 16 * i + (lane & 15), lane >> 4);
+        fal[i] = read_frag(tA, 128 * g + 16 * i + (lane & 15), 4 + (lane >> 4));
+      }
+      load_a(s + 1);
+      SG_H2_SYNC();
+      // MFMA0(s)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          acc[i][jj] = mfma_16x16x32<true>(fwh[jj], fah[i], acc[i][jj]);
+          acc[i][jj] = mfma_16x16x32<true>(fwl[jj], fah[i], acc[i][jj]);
+          acc[i][jj] = mfma_16x16x32<true>(fwh[jj], fal[i], acc[i][jj]);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      SG_H2_SYNC();
+      // READ1(s): A rows 64-127; issue this group's rows of W(s+2) / W(s+3)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fah[i] = read_frag(tA, 128 * g + 64 + 16 * i + (lane & 15), lane >> 4);
+        fal[i] = read_frag(tA, 128 * g + 64 + 16 * i + (lane & 15), 4 + (lane >> 4));
+      }
+      const int uw = s + 2 + g;
+      load_w(uw);
+      SG_H2_SYNC();
+      // MFMA1(s)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          acc[4 + i][jj] = mfma_16x16x32<true>(fwh[jj], fah[i], acc[4 + i][jj]);
+          acc[4 + i][jj] = mfma_16x16x32<true>(fwl[jj], fah[i], acc[4 + i][jj]);
+          acc[4 + i][jj] = mfma_16x16x32<true>(fwh[jj], fal[i], acc[4 + i][jj]);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      if (uw < total) wait_vmcnt<4>(); else wait_vmcnt<0>();             // all but the W pieces just issued
+      SG_H2_SYNC();
+    }
+    // ---- tile end ----
+    if (g == 0) SG_H2_SYNC();                                            // align: every read of this tile's last K step has retired
+    {
+      float* pbase = reinterpret_cast<float*>(ldsA + ((s - 1) & 1) * SLOT);    // the consumed A slot: 8 patches of 8 rows x 68 floats (+pad)
+      epilogue_store8<8, 4, true, 0, SPEC, true>(acc, a, act, c_bf16, 0, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, lane);
+    }
+    cur = nxt; cur_end += nt;
+    if (j + 2 < my_tiles) nxt = make_src(j + 2);
+    SG_H2_SYNC();                                                        // the A slot used as patch is refilled from READ0 of the next step on
+    if (g == 1 && j + 1 < my_tiles) SG_H2_SYNC();                        // re-stagger
+  }
+#undef SG_H2_SYNC
+}
+
+static int launch_h2_persist(const GemmBf16Args& h, hipStream_t s) {
+  const size_t lds = 5 * 256 * 128;                                      // 160 KiB: the whole LDS of a CU
+  using Kern = void (*)(GemmBf16Args, int, int);
+  const Kern kern = (h.c_is_bf16 && !h.residual) ? (h.act == ACT_NONE ? gemm_h2_persist<1> : h.act == ACT_QUICK_GELU ? gemm_h2_persist<2> : gemm_h2_persist<3>)
+                  : (!h.c_is_bf16 && h.residual && h.act == ACT_NONE) ? gemm_h2_persist<4> : gemm_h2_persist<0>;
+  SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
+  const int n_cu = device_cu_count();
+  const int64_t tiles = cdiv(h.M, 256) * cdiv(h.N, 256);
+  SG_REQUIRE(tiles < (1ll << 31), "gemm_h2: grid too large");
+  const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, h, h.act, h.c_is_bf16);
+  return SG_OK;
+}
+
 static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const size_t lds = 4 * (256 + 256) * 32 * 2;
   // instantiation: epilogue form (plain / folded-LayerNorm consumer / producer) x compile-time specialisation of the hot combinations
@@ -1582,8 +1773,12 @@ static int gemm_h2(const GemmBf16Args& a, hipStream_t s) {
   GemmBf16Args h = a;
   h.K = a.K * 2; h.lda = a.lda * 2; h.ldw = a.ldw * 2; h.strideA = a.strideA * 2; h.strideW = a.strideW * 2; h.f16 = 1;
   const bool big = a.M >= 1024 && a.N >= 512 && !(few_tiles(a.M, a.N) && a.batch == 1);
+  // the persistent kernel: batch 1, the vector epilogue, >= 4 K steps per tile (its look-ahead is 3), tile-relative 32-bit offsets;
+  // tuning code 37 keeps the plain ping-pong kernel (A/B measurements)
+  const bool hot_form = (a.c_is_bf16 && !a.residual) || (!a.c_is_bf16 && a.residual && a.act == ACT_NONE);   // the forms with a compile-time epilogue (the run-time one spills)
+  const bool persist = big && vec && hot_form && a.batch == 1 && a.K >= 128 && a.lda * 4 < (1 << 23) && a.ldw * 4 < (1 << 23) && g_gemm_config != 37;
   prof_begin(PROF_GEMM_H2, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
-  const int rc = big ? launch_pingpong(h, vec, s) : launch_ring<128, 128, 2, 2, 2, 0, 64, false, true, false, 0, true>(h, vec, s);
+  const int rc = persist ? launch_h2_persist(h, s) : big ? launch_pingpong(h, vec, s) : launch_ring<128, 128, 2, 2, 2, 0, 64, false, true, false, 0, true>(h, vec, s);
   prof_end(PROF_GEMM_H2, s);
   if (rc != SG_OK) return rc;
   SG_LAUNCH_CHECK();
@@ -1614,7 +1809,7 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
     if (a.ln_stats) SG_REQUIRE(a.ln_c && a.alpha == 1.f && a.c_is_bf16 && !a.residual && !a.rowdot && ((((uintptr_t)a.ln_c) & 15) == 0) && ((((uintptr_t)a.ln_stats) & 7) == 0), "gemm_bf16: ln_stats needs ln_c and alpha 1");
   }
   int cfg = g_gemm_config;
-  if (cfg == 33 || cfg == 34 || cfg == 36) cfg = -1;                    // tuning codes read by capi.hip (MX hand-off / LayerNorm folding off), not tile configurations
+  if (cfg == 33 || cfg == 34 || cfg == 36 || cfg == 37) cfg = -1;                    // tuning codes read by capi.hip (MX hand-off / LayerNorm folding off), not tile configurations
   if (a.rowdot || ln_fold) cfg = 30;
   if (cfg < 0 || a.f16) cfg = (a.rowdot || ln_fold || (a.M >= 1024 && a.N >= 512 && !(few_tiles(a.M, a.N) && a.batch == 1))) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
   if (cfg > 0) {
