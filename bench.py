@@ -10,7 +10,7 @@ One step = one pass of the hot path over one batch of synthetic tiles, inputs re
   'Experimental' self-self attention + similarity map, outlier suppression k=30: configs/base_config.py)
   -> global debias + cosine logits (8 Potsdam queries) -> [all-gather of the per-tile logit maps over ranks]
   -> write-once stitch of this rank's canvas band -> softmax / synonym merge / arg-max labels.
-Scaling: WEAK by default (every rank processes 128 tiles of a scene that grows with the rank count); `--scaling strong` = ONE fixed
+Scaling: WEAK by default (every rank processes 119 tiles -- 7 x 17 windows -- of a scene that grows with the rank count); `--scaling strong` = ONE fixed
 8192 x 8192 scene (961 tiles) whose raster tile list is partitioned over the ranks (pipeline.partition).
 value = all ranks' tiles * 512 * 512 / max-over-ranks time.
 
@@ -39,7 +39,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE, STRIDE = 512, 256
-TILE_COLS, TILE_ROWS_PER_RANK = 16, 8        # weak scaling default: 128 tiles per rank per step (a 2304 x 4352 scene band)
+# weak scaling default: tiles per rank per step = rows x cols of 512-pixel windows at stride 256, chosen per tower so that the 256-row output
+# tiles of the persistent GEMM fill whole rounds of the 256 CUs (T tiles x N tokens / 256 row tiles x N/256 column tiles, every linear of a
+# block): ViT-L/14 7 x 17 = 119 tiles -> 637 row tiles -> 9.95 / 29.86 / 39.81 rounds (128 tiles: 10.70 / 32.11 / 42.81, i.e. a last round
+# with 70 % / 11 % / 81 % of the chip busy).  The same workload per tile; only the launch size is picked for the machine.
+TILE_GRID = {"ViT-L-14": (7, 17), "ViT-B-16": (7, 18), "ViT-H-14": (5, 19)}
+TILE_COLS, TILE_ROWS_PER_RANK = 17, 7        # the ViT-L/14 default: 119 tiles per rank per step (a 2048 x 4608 scene band)
 STRONG_SCENE = 8192                          # strong scaling: one 8192 x 8192 scene = 31 x 31 = 961 tiles
 PEAK_BF16_TFLOPS = 2500.0                    # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0
@@ -83,9 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --tile-rows x --tile-cols tiles per rank, the scene grows with the ranks; strong: one fixed --scene x --scene image, tiles partitioned over the ranks")
     ap.add_argument("--scene", type=int, default=STRONG_SCENE, help="strong scaling: side of the square scene in pixels (8192 -> 961 tiles)")
-    ap.add_argument("--tile-cols", type=int, default=TILE_COLS, help="weak scaling: tiles per scene row")
-    ap.add_argument("--tile-rows", type=int, default=TILE_ROWS_PER_RANK, help="weak scaling: tile rows per rank")
-    ap.add_argument("--tiles-per-launch", type=int, default=0, help="0 = up to 128 of a rank's tiles in one launch of the tower (32 with the upsampler)")
+    ap.add_argument("--tile-cols", type=int, default=0, help="weak scaling: tiles per scene row (0 = the tower's default grid, TILE_GRID)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="weak scaling: tile rows per rank (0 = the tower's default grid)")
+    ap.add_argument("--tiles-per-launch", type=int, default=0, help="0 = up to the tower's machine-filling launch size (TILE_GRID: 119 tiles at ViT-L/14) per launch (32 with the upsampler)")
     ap.add_argument("--streams", type=int, default=1, help="experiment: split a rank's tiles over this many HIP streams (tails of one half overlap the other)")
     ap.add_argument("--upsampler", default=None, choices=["none", "jbu_one", "jbu_stack"],
                     help="per-pixel logits through the SimFeatUp JBU upsampler (BASELINE configs[3]); multi-rank: halo tiles travel point to point")
@@ -250,10 +255,9 @@ def main():
     w = workload_of(args)
     precision = w["precision"]
     jbu = w["upsampler"] != "none"
-    if jbu and args.tile_rows == TILE_ROWS_PER_RANK and args.tile_cols == TILE_COLS:
-        args.tile_rows, args.tile_cols = 4, 8            # per-pixel logits are 11 MB per tile: 32 tiles per rank per step by default
-    if w["vit"] == "ViT-H-14" and args.tile_rows == TILE_ROWS_PER_RANK and args.tile_cols == TILE_COLS and args.scaling == "weak":
-        args.tile_rows = 4                               # 64 tiles per rank per step (twice the work and the workspace per tile)
+    if args.tile_rows <= 0 or args.tile_cols <= 0:
+        # per-pixel logits (upsampler) are 11 MB per tile: 32 tiles per rank per step; otherwise the tower's machine-filling grid
+        args.tile_rows, args.tile_cols = (4, 8) if jbu else TILE_GRID[w["vit"]]
     tile_cols, tile_rows = args.tile_cols, args.tile_rows
 
     # ---- scene geometry: weak = tile_cols x (tile_rows * world) tiles; strong = one fixed square scene ---------------------------------
@@ -270,7 +274,7 @@ def main():
     my = wins[lo:hi] if hi > lo else [wins[0]]            # more ranks than tiles: a dummy so shapes agree
     n_mine = hi - lo
     if args.tiles_per_launch <= 0:
-        args.tiles_per_launch = 32 if jbu else 128
+        args.tiles_per_launch = 32 if jbu else TILE_GRID[w["vit"]][0] * TILE_GRID[w["vit"]][1]      # the machine-filling launch size of the tower
     cfg, pipe, qidx = build_pipeline(device, w, precision, args.tiles_per_launch)
     plan = band_plan(wins, H, world)                                  # canvas bands + the tile range each band needs (pipeline.py)
     yb, need = plan

@@ -14,6 +14,10 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef SG_PS_ABL
+#define SG_PS_ABL 0                                         // tuning builds only (tools/ablate_persist.sh): parts of the persistent GEMM switched off
+#endif
+
 namespace sg {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -838,6 +842,7 @@ static int launch_pp32(const GemmBf16Args& a, hipStream_t s) {
   return SG_OK;
 }
 
+static thread_local int g_persist_grid_cap = 0;             // tuning (sg_set_gemm_config(2000 + n)): at most n workgroups for the persistent kernel (0 = one per CU)
 static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gemm_config(1000 + v)): -1 automatic N-group size, 0 raster order, v > 0 forced N-group size
 // ---- persistent ping-pong: the production kernel for the large ViT linears ---------------------------------------------------------
 // gemm_bf16_pp32's ring (K tile 32, four slots) with three changes measured to matter:
@@ -943,6 +948,19 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       }
       v4[j] = make_float4(v[0], v[1], v[2], v[3]);
     }
+#if SG_PS_ABL == 6
+    // tuning build (WRONG element order by design): what would an epilogue cost that transposes in registers instead of through the LDS
+    // patch?  Same bytes, same full-line store pattern (8 rows x 128 B per instruction), no LDS round trip.
+    if (c_bf16 && NI == 4) {
+      uint4 o0, o1;
+      o0.x = pack_half2<F16>(v4[0].x, v4[0].y); o0.y = pack_half2<F16>(v4[0].z, v4[0].w); o0.z = pack_half2<F16>(v4[1].x, v4[1].y); o0.w = pack_half2<F16>(v4[1].z, v4[1].w);
+      o1.x = pack_half2<F16>(v4[2].x, v4[2].y); o1.y = pack_half2<F16>(v4[2].z, v4[2].w); o1.z = pack_half2<F16>(v4[3].x, v4[3].y); o1.w = pack_half2<F16>(v4[3].z, v4[3].w);
+      const int m = row0 + i * 16 + (lane >> 3), n = col0 + (lane & 7) * 8;
+      if (m < a.M && n < a.N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)m * a.ldc + n) = o0;
+      if (m + 8 < a.M && n < a.N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)(m + 8) * a.ldc + n) = o1;
+      continue;
+    }
+#endif
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {                       // two 8-row strips per 16-row MFMA tile
       if (((lane >> 3) & 1) == hh) {
@@ -967,6 +985,9 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
             store_h2x8(reinterpret_cast<h2_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n, v8);
           } else {
           uint4 o; o.x = pack_half2<F16>(x0.x, x0.y); o.y = pack_half2<F16>(x0.z, x0.w); o.z = pack_half2<F16>(x1.x, x1.y); o.w = pack_half2<F16>(x1.z, x1.w);
+#if SG_PS_ABL == 5
+          if (o.x == 0x12345678u)                              // tuning build: the patch round trip and the packing stay, the store (almost) never happens
+#endif
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = o;
           }
         }
@@ -992,6 +1013,9 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
             x.x += rr.x; x.y += rr.y; x.z += rr.z; x.w += rr.w;
           }
           if (r < 8 && m < a.M && n < a.N)
+#if SG_PS_ABL == 5
+            if (x.x == 1234.5678f)
+#endif
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n) = x;
           if constexpr (PROD) *reinterpret_cast<float4*>(patch + r * LDP + cq) = x;   // the finished values go back into the patch (same lane, same place)
         }
@@ -1137,12 +1161,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
       constexpr bool STEADY = decltype(steady_tag)::value;
       const char* tA = lds + (s & 3) * TILE_B;
       const char* tW = tA + PBM * KT32 * 2;
-      // READ(s)
+      // READ(s)   (SG_PS_ABL, tuning builds only -- WRONG results by design: 1 = no LDS-DMA issue in the steady loop, 2 = no fragment reads,
+      //            3 = no MFMAs, 4 = no epilogue: what each part of a slot costs, tools/ablate_persist.sh)
+#if SG_PS_ABL == 2
+      if (!STEADY || kt == 0) {
+#endif
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) fw[jj] = read_frag32(tW, 64 * wi + 16 * jj + (lane & 15), lane >> 4);
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = read_frag32(tA, 128 * g + 16 * i + (lane & 15), lane >> 4);
-      if constexpr (STEADY) {
+#if SG_PS_ABL == 2
+      }
+#endif
+      if constexpr (STEADY && SG_PS_ABL == 1) {
+        if (g == 1) wait_vmcnt<8>();
+      } else if constexpr (STEADY) {
         auto piece = [&](const bf16_t* const (&src)[2], const int (&dst)[2], int ahead) {
           char* base = lds + ((s + ahead) & 3) * TILE_B;
 #pragma unroll
@@ -1161,7 +1194,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma_16x16x32<F16>(fw[jj], fa[i], acc[i][jj]);
+        for (int jj = 0; jj < 4; ++jj) {
+#if SG_PS_ABL == 3
+          if (STEADY) { asm volatile("" ::"v"(fw[jj]), "v"(fa[i])); continue; }
+#endif
+          acc[i][jj] = mfma_16x16x32<F16>(fw[jj], fa[i], acc[i][jj]);
+        }
       __builtin_amdgcn_s_setprio(0);
       if (g == 0) { if constexpr (STEADY) wait_vmcnt<6>(); else wait_tile(s + 1); }
       SG_PS_SYNC();
@@ -1174,6 +1212,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
     if (g == 0) SG_PS_SYNC();                               // align: every read of this tile's last K tile has retired
     {
       float* patch = reinterpret_cast<float*>(lds + ((s - 1) & 3) * TILE_B) + wave * 576;   // 8 rows x 68 floats (+pad) per wave
+#if SG_PS_ABL == 4
+      if (acc[0][0][0] == 1234.5678f)                                                       // keep the accumulators live, store (almost) nothing
+#endif
       epilogue_store8<8, 4, F16, EPI, SPEC>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
     }
     cur = nxt; cur_end += nt;
@@ -1664,7 +1705,8 @@ static int launch_persist(const GemmBf16Args& a, hipStream_t s) {
   const int n_cu = device_cu_count();
   const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   SG_REQUIRE(tiles < (1ll << 31) && a.batch < 65536, "gemm_bf16: grid too large");
-  const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+  unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+  if (g_persist_grid_cap > 0 && grid > (unsigned)g_persist_grid_cap) grid = (unsigned)g_persist_grid_cap;
   GemmBf16Args b = a;
   // W-panel-resident order where it pays: more N tiles than fit the L2 together and a short K (re-reading the A panels once per
   // N-group must cost less than re-streaming every W panel once per round): the K = 1024 linears with N = 3072 / 4096
@@ -1691,6 +1733,7 @@ static bool few_tiles(int M, int N) {
 bool gemm_bf16_ln_fold_ok(int M, int N, int K) { return M >= 1024 && N >= 512 && N % 64 == 0 && K % 32 == 0 && K / 32 >= 4; }
 bool gemm_bf16_prefers_persistent(int M, int N) { return M >= 1024 && N >= 512 && !few_tiles(M, N); }
 void set_gemm_config(int c) {
+  if (c >= 2000) { g_persist_grid_cap = c - 2000; return; } // experiment: fewer persistent workgroups than CUs (2000 = no cap)
   if (c >= 1000) { g_gemm_order = c - 1001; return; }      // 1000 -> -1 (automatic), 1001 -> 0 (raster), 1001 + v -> N-group size v
   g_gemm_config = c;
 }

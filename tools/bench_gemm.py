@@ -13,6 +13,8 @@ CONFIGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,
 # tile order of the persistent kernel (config 30): GEMM_ORDER = auto | raster | <N-group size>
 _order = os.environ.get("GEMM_ORDER", "auto")
 lib.sg_set_gemm_config(1000 if _order == "auto" else (1001 if _order == "raster" else 1001 + int(_order)))
+if os.environ.get("GEMM_GRID_CAP"):
+    lib.sg_set_gemm_config(2000 + int(os.environ["GEMM_GRID_CAP"]))   # experiment: fewer persistent workgroups than CUs
 ROUNDS, ITERS = 5, 10
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
@@ -38,7 +40,7 @@ for name, m, n, k, act, cbf in SHAPES:
                 x = x + R
             ref = x
         err = ((out - ref).abs().max() / ref.abs().max()).item()
-        assert err < 2e-2 or (cfg >= 10 and cfg != 30), (name, cfg, err)
+        assert err < 2e-2 or (cfg >= 10 and cfg != 30) or os.environ.get("GEMM_NOCHECK"), (name, cfg, err)   # GEMM_NOCHECK: ablated builds (tools/ablate_persist.sh)
     for rnd in range(ROUNDS):
         for cfg in CONFIGS:
             lib.sg_set_gemm_config(cfg)
