@@ -11,6 +11,10 @@ What differs, and why (none of it is on the hot path):
     (segmentor.py:157-174) on the HIP text tower (``sg_text_encode``).  Alternatives: ``text_features=`` ([Q,E]
     tensor / .npy / .pt path) or ``text_encoder=`` (callable: list[str] -> [n,E] tensor); the 80-template
     prompt ensemble is applied here in every case.
+  * ``precision=`` (default ``"f16x2"``): the arithmetic of the tower.  The reference runs ``.half()`` on the GPU (segmentor.py:467) and fp32
+    on the CPU; the default here is the most faithful mode that clears the 50 Mpix/s target -- two f16 planes per operand, three MFMAs
+    per product: the fp32 path's logits (max |dlogit| 5e-7 on the bench tiles) and labels (identical up to fp32 ties) at ~95 Mpix/s for
+    ViT-L/14.  ``"bf16"`` (225 Mpix/s, 5e-3 / 99.4 % labels), ``"f16"``, ``"fp8"`` trade accuracy for speed; ``"f32"`` is the f32-MFMA parity mode.
 """
 from __future__ import annotations
 
@@ -124,7 +128,7 @@ class _HipSegmentorBase(_Base):
 
     def _setup(self, clip_type, vit_type, model_type, name_path, device, ignore_residual, prob_thd, logit_scale, slide_stride,
                slide_crop, cls_token_lambda, bg_idx, apply_sim_feat_up, sim_feat_up_cfg, global_debias_factor=0.0,
-               checkpoint=None, text_features=None, text_encoder: Optional[Callable] = None, precision="bf16",
+               checkpoint=None, text_features=None, text_encoder: Optional[Callable] = None, precision="f16x2",
                synthetic_ok=False, tiles_per_launch=32, jbu_checkpoint_ok=True, tokenizer: Optional[Callable] = None, tile_group=None):
         self.tile_group = tile_group                         # opt-in tile sharding (pipeline.resolve_tile_group); None = off
         if clip_type == "BLIP":
@@ -332,7 +336,7 @@ class SegmentorEx(_HipSegmentorBase):
                  layer_fusion_lambda=0.5, layer_fusion_threshold=0.7, apply_similarity_enhancement=False,
                  similarity_enhancement_cfg=None, result_dir=None, heatmap_dir=None,
                  # -- drop-in extras (see module docstring) --
-                 checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
+                 checkpoint=None, text_features=None, text_encoder=None, precision="f16x2", synthetic_ok=False, tiles_per_launch=32,
                  tokenizer=None, cross_tile_fusion_cfg=None, tile_group=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)
@@ -374,7 +378,7 @@ class Segmentor(_HipSegmentorBase):
     def __init__(self, clip_type, vit_type, model_type, name_path, device=torch.device("cuda"), ignore_residual=True, prob_thd=0.0,
                  logit_scale=50, slide_stride=112, slide_crop=224, cls_token_lambda=0, bg_idx=0, apply_sim_feat_up=True,
                  sim_feat_up_cfg=dict(model_name="jbu_one", model_path="your/model/path"),
-                 checkpoint=None, text_features=None, text_encoder=None, precision="bf16", synthetic_ok=False, tiles_per_launch=32,
+                 checkpoint=None, text_features=None, text_encoder=None, precision="f16x2", synthetic_ok=False, tiles_per_launch=32,
                  tokenizer=None, cross_tile_fusion_cfg=None, tile_group=None, apply_outlier_suppression=False, outlier_suppression_cfg=None):
         data_preprocessor = SegDataPreProcessor(mean=list(Wt.PIXEL_MEAN), std=list(Wt.PIXEL_STD), bgr_to_rgb=True)
         super().__init__(data_preprocessor=data_preprocessor)

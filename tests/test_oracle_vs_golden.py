@@ -290,3 +290,48 @@ def test_layernorm_folding_identity_and_slice_statistics():
     m2 = (q + 64 * (s / 64 - mean[:, None]) ** 2).sum(1)
     assert np.abs(mean - mu[:, 0]).max() < 1e-12 * (1 + np.abs(mu).max())
     assert np.abs(m2 / D - var[:, 0]).max() < 1e-10 * var.max()
+
+
+def test_two_plane_f16_product_is_f32_grade():
+    """The arithmetic SG_PREC_F16X2 relies on (csrc/common.h split_h2, tools/h2_probe.hip on the hardware): x = hi + lo with hi = f16(x),
+    lo = f16(x - hi) carries ~22 significant bits, and hi.hi + hi.lo + lo.hi accumulated in f32 matches an f32 dot product's error,
+    three orders of magnitude below plain f16 -- including small operands whose lo plane lives in the f16 subnormals."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    K = 1024
+    for wscale in (1.0, 0.03):
+        a = rng.standard_normal((16, K)).astype(np.float32)
+        w = (rng.standard_normal((16, K)) * wscale).astype(np.float32)
+        ah, wh = a.astype(np.float16), w.astype(np.float16)
+        al, wl = (a - ah.astype(np.float32)).astype(np.float16), (w - wh.astype(np.float32)).astype(np.float16)
+        rep = np.abs((ah.astype(np.float64) + al.astype(np.float64)) - a).max()
+        assert rep <= max(2.0 ** -21 * np.abs(a).max(), 2.0 ** -24)               # representation error of an element
+        f = lambda x: x.astype(np.float32)
+        three = (f(ah) @ f(wh).T + f(ah) @ f(wl).T + f(al) @ f(wh).T).astype(np.float32)   # f32 accumulation of the three products
+        ref = a.astype(np.float64) @ w.astype(np.float64).T
+        e3 = np.abs(three - ref).max()
+        e32 = np.abs((a @ w.T) - ref).max()
+        e16 = np.abs((f(ah) @ f(wh).T) - ref).max()
+        # f32-grade: within ~1e-6 of the result scale (numpy's blocked f32 matmul, e32, is itself a few 1e-7), > 100x below plain f16
+        assert e3 < 1.5e-6 * np.abs(ref).max() and e3 < 10 * e32 + 1e-6 and e3 < e16 / 100, (wscale, e3, e32, e16)
+
+
+def test_gem_plus_outlier_composition_definition(tiny=None):
+    """BASELINE configs[2] as one forward (oracle/vit.py::gem_forward(outlier_cfg=...)): a composition the reference cannot run (SURVEY R5).
+    Pins the DEFINITION on the tiny GEM tower: (1) without a suppressor it is the reference-pinned GEM forward (vit_tiny-gem fixture, covered
+    above); (2) detection reads the ORDINARY stream's head-averaged attention of block L-2, also when that block is not a dual-stream one
+    (gem_depth 2); (3) the suppression is exactly suppress_outliers on the GEM stream before ln_post."""
+    from clip_decontamination_amd import weights as Wt
+    import numpy as np
+    cfg = Wt.vit_config("tiny-gem")
+    w = OV.to_torch(Wt.make_vit_weights(cfg, seed=0))
+    img = torch.from_numpy(np.random.default_rng(1).standard_normal((2, 3, 48, 48), dtype=np.float32))
+    with torch.no_grad():
+        plain = OV.gem_forward(w, cfg, img, True, 7)
+        comp = OV.gem_forward(w, cfg, img, True, 7, outlier_cfg=dict(top_k=5))
+        shallow = OV.gem_forward(w, cfg, img, True, 2, outlier_cfg=dict(top_k=5))
+    assert comp.shape == plain.shape == shallow.shape
+    changed = (comp - plain).abs().amax(dim=-1) > 1e-6                       # [B, n]: tokens the suppression touched
+    n_changed = changed.sum(dim=1)
+    assert bool((n_changed >= 5).all()) and bool((n_changed <= 5 * 9).all())  # k outliers + at most 8 neighbours each
+    assert torch.isfinite(shallow).all()
