@@ -127,10 +127,21 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
   // With an additive bias (similarity map, shared by the H heads) the order is turned round: the H heads of one (image, query block)
   // run back to back on one XCD, so the 128 x N bias slice (700 kB) is fetched once instead of once per head, which outweighs the
   // K / V re-reads (bias [B,n,n] f32 is 16x the size of K and V together).
+  // Round 3: with enough images per launch (>= 16: two per XCD) an XCD takes WHOLE images and walks each as head groups of 4: for a group,
+  // all query blocks, the 4 heads of a query block back to back.  The K / V of a head group (2 MB at ViT-L/14) then stay in the XCD's L2 for
+  // all 11 query blocks and a bias slice is shared by 4 heads that start together, instead of every query block re-streaming the K / V of all
+  // 16 heads (8.4 MB per image, more than the L2: rocprofv3 FETCH_SIZE 12.1 GB per 128-tile launch against ~2 GB of unique data).
   const int nq = (a.N + QB - 1) / QB;
   const int xw = blockIdx.x & 7, jw = blockIdx.x >> 3;
   int b, hd, qb;
-  if (GENERIC && (EXPER || a.bias != nullptr)) {
+  if (GENERIC && (EXPER || a.bias != nullptr) && a.B >= 16 && (a.H & 3) == 0) {
+    const int hh = jw & 3, t1 = jw >> 2;
+    qb = t1 % nq;
+    const int t2 = t1 / nq, ngrp = a.H >> 2;
+    hd = (t2 % ngrp) * 4 + hh;
+    b = (t2 / ngrp) * 8 + xw;
+    if (b >= a.B) return;
+  } else if (GENERIC && (EXPER || a.bias != nullptr)) {
     const int unit = (jw / a.H) * 8 + xw;
     if (unit >= a.B * nq) return;
     b = unit / nq; qb = unit % nq; hd = jw % a.H;
@@ -511,7 +522,9 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   SG_REQUIRE(a.ctx || !multi, "attention: a log-sum-exp-only pass has one stream");
   if (lds > 64 * 1024) SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t nqb = cdiv(a.N, QB);
-  const int64_t nblk = (generic && a.bias) ? cdiv((int64_t)a.B * nqb, 8) * 8 * a.H : cdiv((int64_t)a.H * a.B, 8) * 8 * nqb;
+  const int64_t nblk = (generic && a.bias) ? ((a.B >= 16 && (a.H & 3) == 0) ? cdiv((int64_t)a.B, 8) * 8 * a.H * nqb     // whole images per XCD (see the kernel)
+                                                                              : cdiv((int64_t)a.B * nqb, 8) * 8 * a.H)
+                                           : cdiv((int64_t)a.H * a.B, 8) * 8 * nqb;
   SG_REQUIRE(nblk < (1ll << 31), "attention: grid too large");
   dim3 grid((unsigned)nblk);
   // algorithmic FLOPs: 2*N*N*dh per (term score) + 2*N*N*dh per stream PV, per (image, head)

@@ -129,6 +129,21 @@ def test_attention(ops, B, N, D, H, variant, prec, tol):
     assert rel_err(out, ref) < tol, rel_err(out, ref)
 
 
+@pytest.mark.parametrize("B,H", [(19, 4), (17, 8), (16, 6)])
+@pytest.mark.parametrize("variant", ["Experimental", "SegEarth"])
+@pytest.mark.parametrize("prec,tol", [("f16x2", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
+def test_attention_with_bias_many_images(ops, B, H, variant, prec, tol):
+    """>= 16 images per launch and heads % 4 == 0: the biased kernels map workgroups as whole images per XCD, head groups of 4, all query
+    blocks of a group (attention.hip); (16, 6) keeps the older (query block, head) order.  N = 300: three query blocks, ragged last key tile."""
+    N, D = 300, 32 * H
+    qkv = rnd(B, N, 3 * D, seed=B + H, scale=1.0)
+    f = torch.nn.functional.normalize(rnd(B, N - 1, 24, seed=9), dim=-1)
+    sim = f @ f.transpose(1, 2)
+    ref, _ = attention_reference(qkv, H, variant, sim, 0.8)
+    out = ops.attention(qkv.to(DEV), H, variant, sim.to(DEV), 0.8, precision=prec)
+    assert rel_err(out, ref) < tol, rel_err(out, ref)
+
+
 @pytest.mark.parametrize("variant", ["NACLIP", "NOnly", "GAV"])
 @pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x2", 2e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
 def test_attention_gaussian_window(ops, variant, prec, tol):

@@ -50,7 +50,14 @@ def main():
         if doms:
             calls = sum(r["calls"] for r in doms)
             avg = sum(r["hbm_bytes_per_launch_high"] * r["calls"] for r in doms) / calls
+            import subprocess
+            try:
+                head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+                dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "clip_decontamination_amd/csrc", "bench.py"], capture_output=True, text=True).stdout.strip())
+            except Exception:
+                head, dirty = "unknown", False
             json.dump({"gemm_bf16_persist": round(avg),
+                       "measured_at_git_head": head + (" + uncommitted kernel / bench changes" if dirty else ""),
                        "per_instantiation": {r["kernel"]: {"calls": r["calls"], "avg_us": r["avg_us"], "hbm_bytes_per_launch_high": r["hbm_bytes_per_launch_high"]} for r in doms},
                        "note": "bytes per launch averaged (call-weighted) over the persistent GEMM launches of a step -- 4 linear shapes, plain / folded-LayerNorm "
                                "consumer / producer epilogues: 2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE, "
