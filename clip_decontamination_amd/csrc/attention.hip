@@ -418,9 +418,9 @@ __global__ __launch_bounds__(256, ((GK != 0 && MULTI) || (DH > 64 && (GK != 0 ||
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         if constexpr (AH2) {
-          const float p8[8] = {sc[8 * f], sc[8 * f + 1], sc[8 * f + 2], sc[8 * f + 3], sc[8 * f + 4], sc[8 * f + 5], sc[8 * f + 6], sc[8 * f + 7]};
-          uint4 ph, pl;
-          split_h2x8(p8, ph, pl);
+          uint4 ph, pl;                                      // probabilities are <= 2^RESCALE_TAU: no saturation needed
+          split_h2_bounded(sc[8 * f], sc[8 * f + 1], ph.x, pl.x); split_h2_bounded(sc[8 * f + 2], sc[8 * f + 3], ph.y, pl.y);
+          split_h2_bounded(sc[8 * f + 4], sc[8 * f + 5], ph.z, pl.z); split_h2_bounded(sc[8 * f + 6], sc[8 * f + 7], ph.w, pl.w);
           pf[f] = __builtin_bit_cast(bf16x8, ph); pfl[f] = __builtin_bit_cast(bf16x8, pl);
         } else if constexpr (F16) {
           f32x8_t fp;                                        // 4 x v_cvt_pk_f16_f32

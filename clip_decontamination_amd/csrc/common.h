@@ -113,6 +113,15 @@ __device__ __forceinline__ void split_h2(float a, float b, uint32_t& hi, uint32_
   hi = __builtin_bit_cast(uint32_t, h);
   lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
 }
+// the same without the saturating clamps, for values known to lie well inside the f16 range (softmax probabilities <= 2^8): 6 instead of 10 VALU per pair
+__device__ __forceinline__ void split_h2_bounded(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f32x2_t v = {a, b};
+  const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+  const f32x2_t back = __builtin_convertvector(h, f32x2_t);
+  const f32x2_t r = {a - back[0], b - back[1]};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+}
 // 8 consecutive elements (one storage group) -> the 32 bytes of the group
 __device__ __forceinline__ void split_h2x8(const float (&v)[8], uint4& hi, uint4& lo) {
   split_h2(v[0], v[1], hi.x, lo.x); split_h2(v[2], v[3], hi.y, lo.y); split_h2(v[4], v[5], hi.z, lo.z); split_h2(v[6], v[7], hi.w, lo.w);
