@@ -23,8 +23,12 @@ ARCH = "gfx950"
 SOURCES = ["capi.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "attention_f16.hip", "attention_h2.hip", "rowops.hip", "patchify.hip", "refine.hip",
            "head.hip", "jbu.hip", "ctd.hip"]
 # the attention loops count vector-issue slots between MFMAs: SLP-packed v_pk_add_f32 / v_pk_mul_f32 cost several plain f32 ops there
-# (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'), so the scalar f32 arithmetic of those units stays scalar
-EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "attention_f16.hip": ["-fno-slp-vectorize"], "attention_h2.hip": ["-fno-slp-vectorize"]}
+# (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'), so the scalar f32 arithmetic of those units stays scalar.
+# jbu.hip: with the Keff arithmetic of jbu_conv_lowres_kernel SLP-packed into v_pk_fma_f32 the kernel was not reproducible from run to
+# run (rare pixels, always the high half of lanes 48..63, only once co-resident workgroups ran different phases); the scalar build is
+# bit-reproducible (tests/test_gpu_repro.py; DESIGN.md section 4 'JBU reproducibility')
+_NO_SLP = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {"attention.hip": _NO_SLP, "attention_f16.hip": _NO_SLP, "attention_h2.hip": _NO_SLP, "jbu.hip": _NO_SLP}
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 
@@ -39,6 +43,7 @@ def hipcc() -> str:
 def _newest_header() -> float:
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "segearth_hip.h"))
+    hs.append(os.path.abspath(__file__))              # the compile flags live here
     return max(os.path.getmtime(h) for h in hs)
 
 

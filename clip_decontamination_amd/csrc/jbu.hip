@@ -415,17 +415,21 @@ __global__ __launch_bounds__(256) void jbu_adaptive_conv_mfma_kernel(const bf16_
 // hi-res tensor and half of the GEMM's K dimension disappear (K 352 -> 160 at r = 5).  Per 8 x 8 pixel block:
 //   1. Wx / Wy tables (dense [8][D][12] f32) from the same cubic_taps() arithmetic as jbu_bicubic_kernel, K rows of the 64 pixels -> LDS
 //   2. Keff per pixel on the VALU: 4 threads per pixel, thread q owns window columns 3q..3q+2: T = K . Wx (registers), Keff = Wy^T . T
-//      -> F [64 px][KP] bf16 (K contiguous)                                  [3 k FMA per pixel, shared by all C channels]
-//   3. per 128-channel chunk: window [pos][128 ch] bf16 copied as it lies in HBM (16-byte pieces, no transposition); the MFMA operand
+//      -> F [64 px][KP] bf16, K slot = q * QW + 3 ly + c for window position (ly, 3q + c): one contiguous run per thread, written with
+//      8 / 16-byte LDS stores                                                 [3 k FMA per pixel, shared by all C channels]
+//      (this unit is built with -fno-slp-vectorize: with the arithmetic packed into v_pk_fma_f32 the kernel was not reproducible from
+//      run to run, see build.py and DESIGN.md section 4 'JBU reproducibility')
+//   3. per 128-channel chunk: window [K slot][128 ch] bf16 copied as it lies in HBM (16-byte pieces, no transposition); the MFMA operand
 //      (8 consecutive window positions of one channel per lane) is fetched with two ds_read_b64_tr_b16 (hardware transpose);
 //      out[64, 128] = F . Win on v_mfma_f32_16x16x32_bf16, operands swapped so a lane owns 4 consecutive channels of one pixel.
 // 65 KB of LDS: two blocks per CU overlap each other's staging and MFMA phases.
 template <int R> struct LowCfg {
   static constexpr int D = 2 * R + 1, D2 = D * D;
   static constexpr int LW = R == 5 ? 12 : 10;          // low-res window side
-  static constexpr int LWP = 12;                        // padded to 4 threads x 3 columns
+  static constexpr int LWP = 16;                        // table row stride: x rows hold thread q's 3 columns at [4q, 4q+3) (16-byte aligned reads), y rows are plain
   static constexpr int OFF = R == 5 ? 4 : 3;            // window origin = block origin / 2 - OFF
-  static constexpr int NPOS = LW * LW;
+  static constexpr int QW = R == 5 ? 36 : 32;          // K slots of one column-owner thread: slot q * QW + 3 ly + c <-> window (ly, 3q + c)
+  static constexpr int NPOS = 4 * QW;
   static constexpr int KP = (NPOS + 31) / 32 * 32;
   static constexpr int LDK = KP + 8;                    // F row stride (bf16)
   static constexpr int LDW = ACM_CC + 16;               // window row stride (bf16): [pos][ch]; 288 B keeps the 4-row transposed reads on distinct banks
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
     for (int k = 0; k < 4; ++k) {
       int c = idx[k] - lorg;
       c = c < 0 ? 0 : (c > LW - 1 ? LW - 1 : c);                           // by construction already inside the window
-      row[c] += wt[k];
+      row[isy ? c : c + c / 3] += wt[k];                                   // x rows: column 3q + j at slot 4q + j
     }
   }
   {
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
   {
     const int p = tid >> 2, q = tid & 3, py = p >> 3, px = p & 7;
     const float* kp = sK + p * D2;
-    const float* wx = sWx + px * D * LWP + 3 * q;
+    const float* wx = sWx + px * D * LWP + 4 * q;
     const float* wy = sWy + py * D * LWP;
     float T[D][3];
 #pragma unroll
@@ -520,13 +524,29 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
         const float wv = wy[i * LWP + ly];
         e[ly][0] += wv * T[i][0]; e[ly][1] += wv * T[i][1]; e[ly][2] += wv * T[i][2];
       }
-    bf16_t* fr = sF + p * LDK;                                             // F does not alias sK / the tables
+    // F row of the pixel, K index = q * QW + 3 ly + c: every thread owns one contiguous, 8-byte aligned run and writes it with wide
+    // stores (window columns >= LW of the last thread carry zero table weights, so those slots are exact zeros)
+    constexpr int QW = L::QW;
+    uint32_t pk[QW / 2];
 #pragma unroll
-    for (int ly = 0; ly < LW; ++ly)
+    for (int j = 0; j < QW / 2; ++j) {
+      const int i0 = 2 * j, i1 = 2 * j + 1;
+      const float v0 = i0 < 3 * LW ? e[i0 / 3 < LW ? i0 / 3 : 0][i0 % 3] : 0.f;
+      const float v1 = i1 < 3 * LW ? e[i1 / 3 < LW ? i1 / 3 : 0][i1 % 3] : 0.f;
+      pk[j] = pack_bf2(v0, v1);
+    }
+    bf16_t* fr = sF + p * LDK + q * QW;                                    // F does not alias sK / the tables
+    if constexpr (QW % 8 == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (3 * q + c < LW) fr[ly * LW + 3 * q + c] = f2bf(e[ly][c]);
-    for (int k = L::NPOS + q; k < KP; k += 4) fr[k] = 0;                   // K padding
+      for (int j = 0; j < QW / 8; ++j) *reinterpret_cast<uint4*>(fr + 8 * j) = make_uint4(pk[4 * j], pk[4 * j + 1], pk[4 * j + 2], pk[4 * j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < QW / 4; ++j) *reinterpret_cast<uint2*>(fr + 4 * j) = make_uint2(pk[2 * j], pk[2 * j + 1]);
+    }
+    if constexpr (KP > L::NPOS) {                                          // K padding: (KP - NPOS) / 4 slots per thread
+      static_assert((KP - L::NPOS) == 16, "padding is written as one 8-byte piece per thread");
+      *reinterpret_cast<uint2*>(sF + p * LDK + L::NPOS + 4 * q) = make_uint2(0u, 0u);
+    }
   }
   const bf16_t* sb = src + (int64_t)b * h * w * C;
   for (int c0 = 0; c0 < C; c0 += ACM_CC) {
@@ -540,7 +560,9 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
       for (int u = 0; u < NS; ++u) {
         const int i = tid + u * 256, pos = i / (ACM_CC / 8), qc = i % (ACM_CC / 8);
         const int pc = pos < L::NPOS ? pos : L::NPOS - 1;                  // K padding rows: F is zero there, any finite value will do
-        int sy = ly0 + pc / LW, sx = lx0 + pc % LW;
+        const int qd = pc / L::QW, rem = pc % L::QW;                       // K slot -> window (ly, lx); unused slots clamp onto the window
+        const int wy_ = rem / 3 < LW ? rem / 3 : LW - 1, wx_ = 3 * qd + rem % 3 < LW ? 3 * qd + rem % 3 : LW - 1;
+        int sy = ly0 + wy_, sx = lx0 + wx_;
         sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy); sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);   // weight 0 outside the image too
         int cc = c0 + 8 * qc; cc = cc + 8 <= C ? cc : C - 8;               // ragged last chunk: a valid duplicate, never stored
         wv[u] = *reinterpret_cast<const uint4*>(sb + ((int64_t)sy * w + sx) * C + cc);

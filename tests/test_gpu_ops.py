@@ -350,6 +350,28 @@ def test_jbu_throughput_mode_lowres_conv_vs_oracle(name, C, gh, gw):
     assert rel < 1.5e-2, rel
 
 
+@pytest.mark.parametrize("name,prec,tol", [("jbu_one", "f32", 2e-4), ("jbu_one", "bf16", 1.5e-2), ("jbu_stack", "bf16", 1.5e-2)])
+def test_jbu_512_launch_shape_vs_oracle(name, prec, tol):
+    """The launch shape of `bench.py --upsampler` / BASELINE configs[3]: a 32 x 32 token grid taken 16x to 512 x 512 pixels (stages 64, 128, 256, 512),
+    on a 64-channel slice so that the oracle (tap loop, no unfold) finishes in seconds.  Every stage's grid, the reflect borders of the 512 stage and the
+    8-tiles-per-launch batching of the product are exercised at the sizes the bench runs; f32 parity path and bf16 throughput path (low-res adaptive conv)."""
+    from clip_decontamination_amd import weights as Wt
+    from clip_decontamination_amd.upsampler import get_upsampler
+    from oracle import vit as OV
+    C, g, B = 64, 32, 2
+    wnp = Wt.make_jbu_weights(name, C, seed=3)
+    src = rnd(B, C, g, g, seed=21)
+    guid = torch.from_numpy(Wt.normalize_tiles(Wt.make_tiles_u8(B, 16 * g, seed=77, smooth=True)))            # [B,3,512,512], normalised as the tiles are
+    with torch.no_grad():
+        ref = torch.cat([OJ.jbu_forward(OV.to_torch(wnp), src[i:i + 1], guid[i:i + 1]) for i in range(B)], 0)
+    up = get_upsampler(name, C, DEV, prec)
+    up.load_state_dict(wnp)
+    out = up(src.to(DEV), guid.to(DEV)).cpu()
+    rel = (out - ref).abs().max().item() / ref.abs().max().item()
+    print(f"JBU 32x32 -> 512x512 [{name} {prec}]: max rel err {rel:.3e}")
+    assert out.shape == (B, C, 512, 512) and rel < tol, rel
+
+
 @pytest.mark.parametrize("use_cls", [False, True])
 def test_jbu_fused_logits_tail_equals_unfused_and_oracle(golden, ops, use_cls):
     """sg_jbu_logits (bf16 throughput mode: row-dot GEMM epilogue + Q-wide f32 product, the [S^2, C] map never written) against
