@@ -413,18 +413,22 @@ __global__ __launch_bounds__(256) void jbu_adaptive_conv_mfma_kernel(const bf16_
 //     Keff = Wy^T . K . Wx        (Wy / Wx: the 4-tap bicubic rows of the reflect-padded hi-res tap rows / columns of the pixel)
 // over a LW x LW low-res window (12 x 12 at r = 5, 10 x 10 at r = 3) instead of the (8+2r)^2 hi-res window: the bicubic kernel, the
 // hi-res tensor and half of the GEMM's K dimension disappear (K 352 -> 160 at r = 5).  Per 8 x 8 pixel block:
-//   1. Wx / Wy tables (dense [8][D][12] f32) from the same cubic_taps() arithmetic as jbu_bicubic_kernel, K rows of the 64 pixels -> LDS
-//   2. Keff per pixel on the VALU: 4 threads per pixel, thread q owns window columns 3q..3q+2: T = K . Wx (registers), Keff = Wy^T . T
+//   1. Wx / Wy tables (dense [8][D][16] f32) from the same cubic_taps() arithmetic as jbu_bicubic_kernel, then packed to f16 PAIRS along
+//      the tap index ([8][D/2][16] dwords); K rows of the 64 pixels -> LDS as f16 rows (pairs along the tap column)
+//   2. Keff per pixel on the VALU with v_dot2c_f32_f16 (two products per instruction, f32 accumulation): 4 threads per pixel, thread q owns
+//      window columns 3q..3q+2: T = K . Wx (registers), T re-paired along its rows, Keff = Wy^T . T
 //      -> F [64 px][KP] bf16, K slot = q * QW + 3 ly + c for window position (ly, 3q + c): one contiguous run per thread, written with
-//      8 / 16-byte LDS stores                                                 [3 k FMA per pixel, shared by all C channels]
-//      (this unit is built with -fno-slp-vectorize: with the arithmetic packed into v_pk_fma_f32 the kernel was not reproducible from
-//      run to run, see build.py and DESIGN.md section 4 'JBU reproducibility')
+//      8 / 16-byte LDS stores                                    [1.5 k dot2 per pixel, shared by all C channels; f16 operands carry 11 bits
+//      against the 8 of the bf16 F they end in]
+//      (history: with f32 operands and the arithmetic SLP-packed into v_pk_fma_f32 this kernel was not reproducible from run to run; the
+//      unit is built with -fno-slp-vectorize, see build.py and DESIGN.md section 4 'JBU reproducibility'; tests/test_gpu_repro.py)
 //   3. per 128-channel chunk: window [K slot][128 ch] bf16 copied as it lies in HBM (16-byte pieces, no transposition); the MFMA operand
 //      (8 consecutive window positions of one channel per lane) is fetched with two ds_read_b64_tr_b16 (hardware transpose);
 //      out[64, 128] = F . Win on v_mfma_f32_16x16x32_bf16, operands swapped so a lane owns 4 consecutive channels of one pixel.
 // 65 KB of LDS: two blocks per CU overlap each other's staging and MFMA phases.
 template <int R> struct LowCfg {
   static constexpr int D = 2 * R + 1, D2 = D * D;
+  static constexpr int DPH = (D + 1) / 2, DP = 2 * DPH; // tap pairs per K row / table column (the odd tap is paired with a zero)
   static constexpr int LW = R == 5 ? 12 : 10;          // low-res window side
   static constexpr int LWP = 16;                        // table row stride: x rows hold thread q's 3 columns at [4q, 4q+3) (16-byte aligned reads), y rows are plain
   static constexpr int OFF = R == 5 ? 4 : 3;            // window origin = block origin / 2 - OFF
@@ -435,21 +439,33 @@ template <int R> struct LowCfg {
   static constexpr int LDW = ACM_CC + 16;               // window row stride (bf16): [pos][ch]; 288 B keeps the 4-row transposed reads on distinct banks
   static constexpr size_t F_BYTES = (size_t)64 * LDK * 2;
   static constexpr size_t W_BYTES = (size_t)KP * LDW * 2;
-  static constexpr size_t K_BYTES = (size_t)64 * D2 * 4 + (size_t)2 * 8 * D * LWP * 4;
+  static constexpr size_t KH_BYTES = (size_t)64 * D * DP * 2;             // K rows, f16
+  static constexpr size_t TF_BYTES = (size_t)2 * 8 * D * LWP * 4;         // f32 tables (build scratch)
+  static constexpr size_t TP_BYTES = (size_t)2 * 8 * DPH * LWP * 4;       // pair-packed tables
+  static constexpr size_t K_BYTES = KH_BYTES + TF_BYTES + TP_BYTES;
   static constexpr size_t LDS = F_BYTES + (W_BYTES > K_BYTES ? W_BYTES : K_BYTES);
+  static_assert(KH_BYTES % 16 == 0 && TF_BYTES % 16 == 0, "LDS sub-buffers stay 16-byte aligned");
 };
+
+__device__ __forceinline__ uint32_t pack_h2_bounded(float lo, float hi) {   // operands known to be far inside the f16 range: no clamps
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ float dot2_f16(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), acc, false);
+}
 
 template <int R>
 __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* __restrict__ src, const float* __restrict__ Kf, int ldk, int h, int w,
                                                                  int C, float* __restrict__ out, bf16_t* __restrict__ out16) {
   using L = LowCfg<R>;
-  constexpr int D = L::D, D2 = L::D2, LW = L::LW, LWP = L::LWP, KP = L::KP, LDK = L::LDK, LDW = L::LDW;
+  constexpr int D = L::D, D2 = L::D2, DPH = L::DPH, DP = L::DP, LW = L::LW, LWP = L::LWP, KP = L::KP, LDK = L::LDK, LDW = L::LDW;
   extern __shared__ __attribute__((aligned(16))) char lc_sm[];
   bf16_t* sF = reinterpret_cast<bf16_t*>(lc_sm);                          // [64][LDK]
   bf16_t* sW = reinterpret_cast<bf16_t*>(lc_sm + L::F_BYTES);            // [KP][LDW]            (chunk loop)
-  float* sK = reinterpret_cast<float*>(lc_sm + L::F_BYTES);              // [64][D2]             (Keff build; aliases sW)
-  float* sWx = sK + 64 * D2;                                              // [8][D][LWP]
-  float* sWy = sWx + 8 * D * LWP;
+  uint16_t* sKh = reinterpret_cast<uint16_t*>(lc_sm + L::F_BYTES);       // [64][D][DP] f16      (Keff build; aliases sW)
+  float* sTf = reinterpret_cast<float*>(lc_sm + L::F_BYTES + L::KH_BYTES);              // [2][8][D][LWP] f32: x tables, y tables
+  uint32_t* sTp = reinterpret_cast<uint32_t*>(lc_sm + L::F_BYTES + L::KH_BYTES + L::TF_BYTES);   // [2][8][DPH][LWP] f16 pairs (taps 2jp, 2jp+1)
   const int H = 2 * h, W = 2 * w;
   const int tiles_x = (W + AC_T - 1) / AC_T;
   const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
     u = reflect_idx(u, size);
     int idx[4]; float wt[4];
     cubic_taps(u, lo_size, size, idx, wt);
-    float* row = (isy ? sWy : sWx) + (pl * D + t) * LWP;
+    float* row = sTf + (isy ? 8 * D * LWP : 0) + (pl * D + t) * LWP;
 #pragma unroll
     for (int c = 0; c < LWP; ++c) row[c] = 0.f;
 #pragma unroll
@@ -493,36 +509,51 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
       const int i = tid + u * 256;
-      if (i < D2 * 64) sK[i] = kv[u];                                      // sK[pxl * D2 + t] with i = pxl * D2 + t
+      const int pxl = i / D2, t = i % D2;
+      if (i < D2 * 64) sKh[(pxl * D + t / D) * DP + t % D] = f2h(kv[u]).bits;    // K values are O(1) softmax-like weights
     }
+    if constexpr (DP > D)                                                   // the zero partner of the odd tap
+      for (int i = tid; i < 64 * D; i += 256) sKh[i * DP + D] = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * 8 * DPH * LWP; i += 256) {                      // tables -> f16 pairs along the tap index
+    const int col = i % LWP, jp = (i / LWP) % DPH, tp = i / (LWP * DPH);   // tp = table * 8 + pixel
+    const float* r0 = sTf + (tp * D + 2 * jp) * LWP + col;
+    sTp[i] = pack_h2_bounded(r0[0], 2 * jp + 1 < D ? r0[LWP] : 0.f);
   }
   __syncthreads();
   // ---- 2. Keff = Wy^T . K . Wx for pixel p, window columns 3q..3q+2 ----
   {
     const int p = tid >> 2, q = tid & 3, py = p >> 3, px = p & 7;
-    const float* kp = sK + p * D2;
-    const float* wx = sWx + px * D * LWP + 4 * q;
-    const float* wy = sWy + py * D * LWP;
-    float T[D][3];
+    const uint32_t* kp = reinterpret_cast<const uint32_t*>(sKh) + p * D * DPH;
+    const uint32_t* wx = sTp + px * DPH * LWP + 4 * q;
+    const uint32_t* wy = sTp + (8 + py) * DPH * LWP;
+    float T[DP][3];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const float kv = kp[i * D + j];
-        t0 += kv * wx[j * LWP]; t1 += kv * wx[j * LWP + 1]; t2 += kv * wx[j * LWP + 2];
+      for (int jp = 0; jp < DPH; ++jp) {
+        const uint32_t k2 = kp[i * DPH + jp];
+        t0 = dot2_f16(k2, wx[jp * LWP], t0); t1 = dot2_f16(k2, wx[jp * LWP + 1], t1); t2 = dot2_f16(k2, wx[jp * LWP + 2], t2);
       }
       T[i][0] = t0; T[i][1] = t1; T[i][2] = t2;
     }
+    if constexpr (DP > D) { T[D][0] = 0.f; T[D][1] = 0.f; T[D][2] = 0.f; }
+    uint32_t T2[DPH][3];                                                   // rows (2 ip, 2 ip + 1) of T as f16 pairs
+#pragma unroll
+    for (int ip = 0; ip < DPH; ++ip)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) T2[ip][c] = pack_h2_bounded(T[2 * ip][c], T[2 * ip + 1][c]);
     float e[LW][3];
 #pragma unroll
     for (int ly = 0; ly < LW; ++ly) { e[ly][0] = 0.f; e[ly][1] = 0.f; e[ly][2] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < D; ++i)
+    for (int ip = 0; ip < DPH; ++ip)
 #pragma unroll
       for (int ly = 0; ly < LW; ++ly) {
-        const float wv = wy[i * LWP + ly];
-        e[ly][0] += wv * T[i][0]; e[ly][1] += wv * T[i][1]; e[ly][2] += wv * T[i][2];
+        const uint32_t wv = wy[ip * LWP + ly];
+        e[ly][0] = dot2_f16(wv, T2[ip][0], e[ly][0]); e[ly][1] = dot2_f16(wv, T2[ip][1], e[ly][1]); e[ly][2] = dot2_f16(wv, T2[ip][2], e[ly][2]);
       }
     // F row of the pixel, K index = q * QW + 3 ly + c: every thread owns one contiguous, 8-byte aligned run and writes it with wide
     // stores (window columns >= LW of the last thread carry zero table weights, so those slots are exact zeros)
