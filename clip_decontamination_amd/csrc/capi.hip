@@ -253,7 +253,7 @@ static int linear_ln_producer(int hk, const void* A, int64_t lda, const void* W,
                               void* copy16, float* slice_stats, int M, int N, int K, hipStream_t s) {
   GemmBf16Args g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = K; g.bias = bias; g.residual = residual; g.ldr = ldc;
-  g.C = C; g.ldc = ldc; g.c_is_bf16 = 0; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = ACT_NONE; g.alpha = 1.f; g.f16 = hk == HK_F16;
+  g.C = C; g.ldc = ldc; g.c_is_bf16 = 0; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = ACT_NONE; g.alpha = 1.f; g.f16 = hk == HK_F16; g.h2 = hk == HK_F16X2;
   g.copy16 = copy16; g.ld16 = N; g.row_stats = slice_stats;
   return gemm_bf16(g, s);
 }
@@ -261,7 +261,7 @@ static int linear_ln_consumer(int hk, const void* A, int64_t lda, const void* Wf
                               void* C, int64_t ldc, int M, int N, int K, int act, hipStream_t s) {
   GemmBf16Args g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)Wf; g.ldw = K; g.bias = bias_f;
-  g.C = C; g.ldc = ldc; g.c_is_bf16 = 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f; g.f16 = hk == HK_F16;
+  g.C = C; g.ldc = ldc; g.c_is_bf16 = 1; g.M = M; g.N = N; g.K = K; g.batch = 1; g.act = act; g.alpha = 1.f; g.f16 = hk == HK_F16; g.h2 = hk == HK_F16X2;
   g.ln_stats = mean_rstd; g.ln_c = c_vec;
   return gemm_bf16(g, s);
 }
@@ -350,7 +350,7 @@ static size_t plan(const sg_context* c, int B, int gh, int gw, const sg_forward_
   p.hbuf = b.take(R * d.mlp_width * e);
   p.x8 = p.h8 = p.hmx = nullptr; p.sx8 = p.sh8 = nullptr;
   p.ln_slice = p.ln_rows = nullptr;
-  if ((c->hk == HK_BF16 || c->hk == HK_F16) && !c->fp8 && d.width % 64 == 0) { p.ln_slice = b.get<float>(R * (d.width / 64) * 2); p.ln_rows = b.get<float>(R * 2); }
+  if (c->hk != HK_F32 && !c->fp8 && d.width % 64 == 0) { p.ln_slice = b.get<float>(R * (d.width / 64) * 2); p.ln_rows = b.get<float>(R * 2); }
   if (c->fp8) {
     p.x8 = (uint8_t*)b.take(R * d.width); p.sx8 = b.get<float>(R);
     p.h8 = (uint8_t*)b.take(R * d.mlp_width); p.sh8 = b.get<float>(R);
@@ -517,7 +517,7 @@ extern "C" int sg_create(sg_context** out, int device, const sg_vit_desc* desc) 
       L.b_qkv = bb.get<float>(3 * D); L.b_out = bb.get<float>(D); L.b_fc = bb.get<float>(M); L.b_proj = bb.get<float>(D);
       L.ln1_g = bb.get<float>(D); L.ln1_b = bb.get<float>(D); L.ln2_g = bb.get<float>(D); L.ln2_b = bb.get<float>(D);
       L.w_qkv8 = L.w_fc8 = L.w_proj8 = nullptr; L.s_qkv = L.s_fc = L.s_proj = nullptr;
-      if ((c->hk == HK_BF16 || c->hk == HK_F16) && !c->fp8) {     // folded-LayerNorm operands exist for the 2-byte modes only
+      if (c->hk != HK_F32 && !c->fp8) {     // folded-LayerNorm operands exist for the 2-byte modes and the two-plane f16 mode
         L.w_qkv_f = bb.take((size_t)3 * D * D * e); L.w_fc_f = bb.take((size_t)M * D * e);
         L.c_qkv = bb.get<float>(3 * D); L.bf_qkv = bb.get<float>(3 * D); L.c_fc = bb.get<float>(M); L.bf_fc = bb.get<float>(M);
       }
@@ -1144,25 +1144,26 @@ extern "C" int sg_op_linear(const float* A, const float* W, const float* bias, c
 // x_new = x + A.W1^T + b1;  y = act(LayerNorm(x_new; gamma, beta).W2^T + b2)  -- the residual GEMM -> LayerNorm -> GEMM chain of a block
 // (out-proj -> ln_2 -> fc, proj -> ln_1 -> QKV), either with the LayerNorm as its own pass (fold = 0) or folded into the two GEMMs
 // (fold = 1: 2-byte copy + slice statistics out of the first epilogue, (mean, rstd) and the gamma-folded weight in the second).
-// 2-byte precisions only; M >= 1024, D >= 512, D % 64 == 0, N2 >= 512 with fold.  All operands f32 on the device.
+// 2-byte and two-plane precisions; M >= 1024, D >= 512, D % 64 == 0, N2 >= 512 with fold.  All operands f32 on the device.
 extern "C" size_t sg_op_ln_chain_scratch_bytes(int M, int K1, int D, int N2) {
   const size_t K1p = align_up((size_t)K1, 64);
-  return align_up((size_t)M * K1p * 2, 256) + align_up((size_t)D * K1p * 2, 256) + align_up((size_t)M * D * 2, 256) + align_up((size_t)N2 * D * 2, 256) +
-         align_up((size_t)M * N2 * 2, 256) + align_up((size_t)M * (D / 64 + 1) * 8, 256) + align_up((size_t)M * 8, 256) + 2 * align_up((size_t)N2 * 4, 256) + 4096;
+  return align_up((size_t)M * K1p * 4, 256) + align_up((size_t)D * K1p * 4, 256) + align_up((size_t)M * D * 4, 256) + align_up((size_t)N2 * D * 4, 256) +
+         align_up((size_t)M * N2 * 4, 256) + align_up((size_t)M * (D / 64 + 1) * 8, 256) + align_up((size_t)M * 8, 256) + 2 * align_up((size_t)N2 * 4, 256) + 4096;
 }
 extern "C" int sg_op_ln_chain(const float* A, const float* W1, const float* b1, float* x, const float* gamma, const float* beta, const float* W2,
                               const float* b2, float* y, int M, int K1, int D, int N2, int act, int precision, int fold, void* scratch,
                               size_t scratch_bytes, sg_stream st) {
   SG_REQUIRE(A && W1 && x && gamma && beta && W2 && y && scratch, "sg_op_ln_chain: null pointer");
-  SG_REQUIRE(precision == SG_PREC_BF16 || precision == SG_PREC_F16, "sg_op_ln_chain: 2-byte precisions only");
+  SG_REQUIRE(precision == SG_PREC_BF16 || precision == SG_PREC_F16 || precision == SG_PREC_F16X2, "sg_op_ln_chain: 2-byte and two-plane precisions only");
   SG_REQUIRE(D % 64 == 0, "sg_op_ln_chain: D %% 64 != 0");
   if (scratch_bytes < sg_op_ln_chain_scratch_bytes(M, K1, D, N2)) return fail(SG_ERR_STATE, "sg_op_ln_chain: scratch too small");
   hipStream_t s = as_stream(st);
-  const int hk = precision == SG_PREC_F16 ? HK_F16 : HK_BF16;
+  const int hk = hk_of_precision(precision);
+  const size_t e = hk_esz(hk);
   const int K1p = (int)align_up(K1, 64);
   Bump b(scratch, 0, false);
-  void* a16 = b.take((size_t)M * K1p * 2); void* w116 = b.take((size_t)D * K1p * 2); void* xn = b.take((size_t)M * D * 2);
-  void* w216 = b.take((size_t)N2 * D * 2); void* y16 = b.take((size_t)M * N2 * 2);
+  void* a16 = b.take((size_t)M * K1p * e); void* w116 = b.take((size_t)D * K1p * e); void* xn = b.take((size_t)M * D * e);
+  void* w216 = b.take((size_t)N2 * D * e); void* y16 = b.take((size_t)M * N2 * e);
   float* slice = b.get<float>((size_t)M * (D / 64) * 2); float* rows = b.get<float>((size_t)M * 2);
   float* cvec = b.get<float>(N2); float* bf = b.get<float>(N2);
   SG_TRY(pack_rows(A, M, K1, K1, a16, K1p, hk, s));

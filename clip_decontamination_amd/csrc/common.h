@@ -91,6 +91,15 @@ __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
   const f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -F16_MAX, F16_MAX), __builtin_amdgcn_fmed3f(hi, -F16_MAX, F16_MAX)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
+// Sums over aligned groups of 8 / 16 lanes, result in every lane of the group, on DPP (data-parallel primitives: the add reads its second
+// operand from another lane, one VALU instruction) instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 -- an LDS-queue round trip
+// per step.  Steps: quad xor 1, quad xor 2, half-row mirror (i <-> 7 - i: pairs the two quads), row mirror (i <-> 15 - i: pairs the two
+// halves).  Same pairs in the first two steps and commutative adds afterwards: bit-identical to the xor butterfly.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8_dpp(float v) { v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); return v; }
+__device__ __forceinline__ float sum16_dpp(float v) { v = sum8_dpp(v); v += dpp_f32<0x140>(v); return v; }
 // half-precision kind of a buffer / kernel: 0 = f32, 1 = bf16, 2 = f16, 3 = two-plane f16 (every `int ..._bf16` flag of the internal ops takes these values)
 enum HalfKind { HK_F32 = 0, HK_BF16 = 1, HK_F16 = 2, HK_F16X2 = 3 };
 
@@ -182,6 +191,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // throughput-mode QuickGELU: x * rcp(1 + 2^(-1.702 log2e x)) -- v_exp_f32 + v_rcp_f32 (1 ulp each), inputs end up in bf16 anyway
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x)); }
 __device__ __forceinline__ float quick_gelu_exact(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }
+// the two-plane mode's QuickGELU: the reference's own first rounding (t = -1.702 x), then e^t on the hardware exponential with the log2(e)
+// product carried in two pieces (argument error << 1 ulp) and the hardware reciprocal (1 ulp) in place of expf + IEEE division: 7 issue slots
+// instead of ~25, within 2 ulp of quick_gelu_exact (tests/test_gpu_ops.py::test_linear f16x2 cases hold the GEMM + activation to 2e-5 of f64)
+__device__ __forceinline__ float quick_gelu_split(float x) {
+  const float t = -1.702f * x;
+  const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(t, 1.44269502162933349609f, t * 1.92596299112661746e-8f));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 __device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // The 2-byte / fp8 GEMM epilogues (whose results are rounded to 8-11 mantissa bits anyway): erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7 absolute) on the hardware exp2 / rcp -- about a third of erff's instructions.  Parity mode keeps erff.
@@ -212,7 +229,7 @@ struct GemmBf16Args {
   void* C; int64_t ldc; int64_t strideC; int c_is_bf16;   // C: 0 = f32, 1 = the operands' 2-byte type (bf16, or f16 when `f16` is set)
   int f16;                                            // operands (and a 2-byte C) are IEEE f16 instead of bf16: SG_PREC_F16
   int h2;                                             // SG_PREC_F16X2: A, W (and C when c_is_bf16) are two-plane f16 (h2_t: 4 bytes per element, lda / ldw / ldc /
-                                                      // strides in ELEMENTS, multiples of 8); K % 32 == 0; exact activations; no folded-LayerNorm / row-dot / fp8 forms
+                                                      // strides in ELEMENTS, multiples of 8); K % 32 == 0; f32-grade activations; folded-LayerNorm forms as below (copy16 two-plane); no row-dot / fp8 forms
   int M, N, K, batch, act;
   float alpha;                                        // applied to the accumulator before bias
   // fp8 mode (fp8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K % 128 == 0); lda / ldw / K stay in ELEMENTS (= bytes);

@@ -18,6 +18,9 @@
 #define SG_PS_ABL 0                                         // tuning builds only (tools/ablate_persist.sh): parts of the persistent GEMM switched off
 #endif
 
+#ifndef SG_H2_PROD_ABL
+#define SG_H2_PROD_ABL 0   // tuning builds only (tools): the two-plane producer epilogue without its copy (1), its statistics (2), both (3)
+#endif
 namespace sg {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -186,7 +189,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
                     acc[i][j][2] * (al * cs4[j].z) + bias4[j].z, acc[i][j][3] * (al * cs4[j].w) + bias4[j].w};
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? quick_gelu_exact(v[e]) : quick_gelu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? quick_gelu_split(v[e]) : quick_gelu(v[e]);
       } else if (act == ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = SPLIT ? erf_gelu(v[e]) : erf_gelu_fast(v[e]);
@@ -208,7 +211,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
           const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
           float am = fmaxf(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fmaxf(fabsf(x0.z), fabsf(x0.w))),
                            fmaxf(fmaxf(fabsf(x1.x), fabsf(x1.y)), fmaxf(fabsf(x1.z), fabsf(x1.w))));
-          am = fmaxf(am, __shfl_xor(am, 1, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64));
+          am = fmaxf(am, dpp_f32<0xB1>(am)); am = fmaxf(am, dpp_f32<0x4E>(am));   // quad xor 1, quad xor 2
           // smallest power of two 2^(E-127) with amax / 2^(E-127) <= 448 = 1.75 * 2^8: exponent of amax - 8, + 1 if its mantissa exceeds 1.75's
           const uint32_t ab = __float_as_uint(am);
           int E = (int)(ab >> 23) - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0);
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_ring(GemmBf16Args a
           if (n + e >= a.N) break;
           float x = v[e];
           if (a.bias) x += a.bias[n + e];
-          if (act == ACT_QUICK_GELU) x = SPLIT ? quick_gelu_exact(x) : quick_gelu(x);
+          if (act == ACT_QUICK_GELU) x = SPLIT ? quick_gelu_split(x) : quick_gelu(x);
           else if (act == ACT_GELU) x = SPLIT ? erf_gelu(x) : erf_gelu_fast(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
           if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pingpong(GemmBf16Args a, int ac
           if (n + e >= a.N) break;
           float x = v[e];
           if (a.bias) x += a.bias[n + e];
-          if (act == ACT_QUICK_GELU) x = SPLIT ? quick_gelu_exact(x) : quick_gelu(x);
+          if (act == ACT_QUICK_GELU) x = SPLIT ? quick_gelu_split(x) : quick_gelu(x);
           else if (act == ACT_GELU) x = SPLIT ? erf_gelu(x) : erf_gelu_fast(x);
           if (res) x += res[(int64_t)m * a.ldr + n + e];
           if (c_bf16) reinterpret_cast<bf16_t*>(a.C)[(int64_t)z * a.strideC + (int64_t)m * a.ldc + n + e] = F16 ? f2h(x).bits : f2bf(x);
@@ -866,7 +869,7 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 template <int MI, int NI, bool F16, int MODE = 0, int SPEC = 0, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act_rt, int c_bf16_rt, int z, int row0,
                                                 int col0, float* patch, int lane) {
-  static_assert(!SPLIT || (MODE == 0 && SPEC != 5), "two-plane f16: plain epilogues only (no folded LayerNorm, no row-dot form)");
+  static_assert(!SPLIT || SPEC != 5, "two-plane f16: no row-dot form");
   constexpr bool LN = MODE == 1, PROD = MODE == 2;
   // SPEC > 0: activation (SPEC - 1), output type (2-byte in MODE 0 / 1, f32 in MODE 2) and the presence of a residual (MODE 2 only) are
   // compile-time constants -- straight-line strips without the run-time branches (measured on the QKV shape: -3.3 %; overlapping the
@@ -941,7 +944,7 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
       }
       if (act == ACT_QUICK_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? quick_gelu_exact(v[e]) : quick_gelu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = SPLIT ? quick_gelu_split(v[e]) : quick_gelu(v[e]);
       } else if (act == ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = SPLIT ? erf_gelu(v[e]) : erf_gelu_fast(v[e]);
@@ -1003,8 +1006,11 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           if (RDOT || (SPEC == 0 && !PROD && a.rowdot)) {    // row-dot epilogue (wave-uniform): v * (2 r + v) summed over this wave's 64 columns
             const float4 rr = rbuf[t % RD][r0 / RPP];
             float d = x.x * (2.f * rr.x + x.x) + x.y * (2.f * rr.y + x.y) + x.z * (2.f * rr.z + x.z) + x.w * (2.f * rr.w + x.w);
+            if constexpr (LPR == 16) d = sum16_dpp(d);
+            else {
 #pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+              for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+            }
             if ((lane % LPR) == 0 && m < a.M && col0 < a.N) a.rowdot[(int64_t)m * a.rowdot_ld + (col0 >> 6)] = d;   // col0 >= N: a wave past the last 64-column slice (N % 256 != 0) owns no slot
             continue;
           }
@@ -1029,15 +1035,26 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           const float4 y0 = *reinterpret_cast<const float4*>(patch + r8 * LDP + c8);
           const float4 y1 = *reinterpret_cast<const float4*>(patch + r8 * LDP + c8 + 4);
           if (m8 < a.M && n8 < a.N) {
-            uint4 o; o.x = pack_half2<F16>(y0.x, y0.y); o.y = pack_half2<F16>(y0.z, y0.w); o.z = pack_half2<F16>(y1.x, y1.y); o.w = pack_half2<F16>(y1.z, y1.w);
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.copy16) + (int64_t)m8 * a.ld16 + n8) = o;
+            if constexpr (SPLIT) {
+              const float v8[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#if SG_H2_PROD_ABL == 1 || SG_H2_PROD_ABL == 3
+              if (y0.x == 1234.5678f)
+#endif
+              store_h2x8(reinterpret_cast<h2_t*>(a.copy16) + (int64_t)m8 * a.ld16 + n8, v8);
+            } else {
+              uint4 o; o.x = pack_half2<F16>(y0.x, y0.y); o.y = pack_half2<F16>(y0.z, y0.w); o.z = pack_half2<F16>(y1.x, y1.y); o.w = pack_half2<F16>(y1.z, y1.w);
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.copy16) + (int64_t)m8 * a.ld16 + n8) = o;
+            }
           }
+#if SG_H2_PROD_ABL == 2 || SG_H2_PROD_ABL == 3
+          if constexpr (SPLIT) continue;
+#endif
           float sm = ((y0.x + y0.y) + (y0.z + y0.w)) + ((y1.x + y1.y) + (y1.z + y1.w));
-          sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+          sm = sum8_dpp(sm);
           const float mu = sm * (1.0f / 64.0f);
           const float e0 = y0.x - mu, e1 = y0.y - mu, e2 = y0.z - mu, e3 = y0.w - mu, e4 = y1.x - mu, e5 = y1.y - mu, e6 = y1.z - mu, e7 = y1.w - mu;
           float sq = ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7));
-          sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+          sq = sum8_dpp(sq);
           if ((lane & 7) == 0 && m8 < a.M && col0 < a.N)      // col0 >= N (N % 256 != 0): this wave's slice does not exist -- its slot would be row m8+1's
             *reinterpret_cast<float2*>(a.row_stats + ((int64_t)m8 * (a.N >> 6) + (col0 >> 6)) * 2) = make_float2(sm, sq);
         }
@@ -1511,7 +1528,7 @@ static int launch_fp8_persist(const GemmBf16Args& a, hipStream_t s) {
 // `a` arrives as gemm_h2 prepared it: K, lda, ldw in f16 UNITS (2 x the element counts), C / residual strides in elements.
 // SPEC as epilogue_store8's: 0 = every choice at run time, 1 / 2 / 3 = two-plane output after no activation / QuickGELU / GELU (QKV, fc),
 // 4 = f32 output + f32 residual (out-proj, proj).
-template <int SPEC>
+template <int SPEC, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_h2_persist(GemmBf16Args a, int act, int c_bf16) {
   constexpr int PBM = 256, PBN = 256, KB = 128;                          // K step in bytes
   constexpr int SLOT = 256 * KB;                                         // 32 KiB
@@ -1656,7 +1673,7 @@ __global__ __launch_bounds__(512) void gemm_h2_persist(GemmBf16Args a, int act, 
     if (g == 0) SG_H2_SYNC();                                            // align: every read of this tile's last K step has retired
     {
       float* pbase = reinterpret_cast<float*>(ldsA + ((s - 1) & 1) * SLOT);    // the consumed A slot: 8 patches of 8 rows x 68 floats (+pad)
-      epilogue_store8<8, 4, true, 0, SPEC, true>(acc, a, act, c_bf16, 0, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, lane);
+      epilogue_store8<8, 4, true, EPI, SPEC, true>(acc, a, act, c_bf16, 0, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, lane);
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);
@@ -1669,8 +1686,13 @@ __global__ __launch_bounds__(512) void gemm_h2_persist(GemmBf16Args a, int act, 
 static int launch_h2_persist(const GemmBf16Args& h, hipStream_t s) {
   const size_t lds = 5 * 256 * 128;                                      // 160 KiB: the whole LDS of a CU
   using Kern = void (*)(GemmBf16Args, int, int);
-  const Kern kern = (h.c_is_bf16 && !h.residual) ? (h.act == ACT_NONE ? gemm_h2_persist<1> : h.act == ACT_QUICK_GELU ? gemm_h2_persist<2> : gemm_h2_persist<3>)
-                  : (!h.c_is_bf16 && h.residual && h.act == ACT_NONE) ? gemm_h2_persist<4> : gemm_h2_persist<0>;
+  // epilogue form: folded-LayerNorm consumer (two-plane output, activation per layer kind) / producer (f32 + residual, two-plane copy, slice
+  // statistics) / plain
+  Kern kern;
+  if (h.ln_stats) kern = h.act == ACT_NONE ? gemm_h2_persist<1, 1> : h.act == ACT_QUICK_GELU ? gemm_h2_persist<2, 1> : gemm_h2_persist<3, 1>;
+  else if (h.copy16) kern = gemm_h2_persist<1, 2>;
+  else kern = (h.c_is_bf16 && !h.residual) ? (h.act == ACT_NONE ? gemm_h2_persist<1> : h.act == ACT_QUICK_GELU ? gemm_h2_persist<2> : gemm_h2_persist<3>)
+            : (!h.c_is_bf16 && h.residual && h.act == ACT_NONE) ? gemm_h2_persist<4> : gemm_h2_persist<0>;
   SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int n_cu = device_cu_count();
   const int64_t tiles = cdiv(h.M, 256) * cdiv(h.N, 256);
@@ -1803,8 +1825,8 @@ static int gemm_fp8(const GemmBf16Args& a, hipStream_t s) {
 
 // SG_PREC_F16X2: two-plane f16 operands (common.h h2_t).  The kernels see the same bytes as f16 matrices of twice the width.
 static int gemm_h2(const GemmBf16Args& a, hipStream_t s) {
-  SG_REQUIRE(!a.fp8 && !a.copy16 && !a.ln_stats && !a.rowdot && !a.row_scale && !a.col_scale && !a.a_mx && !a.c_mx,
-             "gemm_h2: the fp8 / folded-LayerNorm / row-dot forms do not exist for two-plane f16 operands");
+  SG_REQUIRE(!a.fp8 && !a.rowdot && !a.row_scale && !a.col_scale && !a.a_mx && !a.c_mx,
+             "gemm_h2: the fp8 / row-dot forms do not exist for two-plane f16 operands");
   SG_REQUIRE(a.K % 32 == 0, "gemm_h2: K=%d must be a multiple of 32 (pad the operands)", a.K);
   SG_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.strideA % 8 == 0 && a.strideW % 8 == 0, "gemm_h2: operand strides must be multiples of 8 elements (32-byte storage groups)");
   SG_REQUIRE((((uintptr_t)a.A) & 31) == 0 && (((uintptr_t)a.W) & 31) == 0, "gemm_h2: operands must be 32-byte aligned");
@@ -1819,7 +1841,16 @@ static int gemm_h2(const GemmBf16Args& a, hipStream_t s) {
   // the persistent kernel: batch 1, the vector epilogue, >= 4 K steps per tile (its look-ahead is 3), tile-relative 32-bit offsets;
   // tuning code 37 keeps the plain ping-pong kernel (A/B measurements)
   const bool hot_form = (a.c_is_bf16 && !a.residual) || (!a.c_is_bf16 && a.residual && a.act == ACT_NONE);   // the forms with a compile-time epilogue (the run-time one spills)
-  const bool persist = big && vec && hot_form && a.batch == 1 && a.K >= 128 && a.lda * 4 < (1 << 23) && a.ldw * 4 < (1 << 23) && g_gemm_config != 37;
+  const bool fits = a.batch == 1 && a.K >= 128 && a.lda * 4 < (1 << 23) && a.ldw * 4 < (1 << 23);
+  const bool ln_fold = a.copy16 != nullptr || a.ln_stats != nullptr;   // folded LayerNorm (round 3): the persistent kernel's own epilogue forms, as in the 2-byte modes
+  if (ln_fold) {
+    SG_REQUIRE(vec && fits && gemm_bf16_ln_fold_ok(a.M, a.N, a.K), "gemm_h2: the folded-LayerNorm epilogues need the persistent kernel (M >= 1024, N >= 512, K >= 128, batch 1)");
+    if (a.copy16) SG_REQUIRE(a.row_stats && !a.c_is_bf16 && a.residual && a.act == ACT_NONE && a.N % 64 == 0 && a.ld16 % 8 == 0 && ((((uintptr_t)a.copy16) & 31) == 0),
+                             "gemm_h2: copy16 needs row_stats, an f32 C with residual, no activation and N %% 64 == 0");
+    if (a.ln_stats) SG_REQUIRE(a.ln_c && a.alpha == 1.f && a.c_is_bf16 && !a.residual && ((((uintptr_t)a.ln_c) & 15) == 0) && ((((uintptr_t)a.ln_stats) & 7) == 0),
+                               "gemm_h2: ln_stats needs ln_c, alpha 1 and a two-plane C");
+  }
+  const bool persist = ln_fold || (big && vec && hot_form && fits && g_gemm_config != 37);
   prof_begin(PROF_GEMM_H2, 2.0 * a.M * (double)a.N * a.K * a.batch, s);
   const int rc = persist ? launch_h2_persist(h, s) : big ? launch_pingpong(h, vec, s) : launch_ring<128, 128, 2, 2, 2, 0, 64, false, true, false, 0, true>(h, vec, s);
   prof_end(PROF_GEMM_H2, s);

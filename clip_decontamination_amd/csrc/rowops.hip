@@ -387,11 +387,31 @@ __global__ __launch_bounds__(256) void fold_ln_weight_kernel(const float* __rest
   cs = wave_sum(cs); bs = wave_sum(bs);
   if (lane == 0) { c[n] = cs; bias_f[n] = (bias ? bias[n] : 0.f) + bs; }
 }
+// two-plane f16: W' = hi + lo carries 22 bits; c sums exactly the two planes the GEMM multiplies with
+__global__ __launch_bounds__(256) void fold_ln_weight_h2_kernel(const float* __restrict__ W, int N, int K, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ bias, h2_t* __restrict__ Wp,
+                                                                float* __restrict__ c, float* __restrict__ bias_f) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float cs = 0.f, bs = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(int64_t)n * K + k];
+    st_elem<h2_t>(Wp + (int64_t)n * K, k, w * gamma[k]);
+    cs += ld_elem<h2_t>(Wp + (int64_t)n * K, k);                          // the same thread's own store
+    bs += beta[k] * w;
+  }
+  cs = wave_sum(cs); bs = wave_sum(bs);
+  if (lane == 0) { c[n] = cs; bias_f[n] = (bias ? bias[n] : 0.f) + bs; }
+}
 int fold_ln_weight(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, int hk, void* Wp, float* c,
                    float* bias_f, hipStream_t s) {
-  SG_REQUIRE(hk == HK_BF16 || hk == HK_F16, "fold_ln_weight: 2-byte compute dtypes only");
+  SG_REQUIRE(hk == HK_BF16 || hk == HK_F16 || hk == HK_F16X2, "fold_ln_weight: 2-byte and two-plane compute dtypes only");
   const dim3 grid((unsigned)cdiv(N, 4));
-  if (hk == HK_F16) hipLaunchKernelGGL(fold_ln_weight_kernel<f16_t>, grid, dim3(256), 0, s, W, N, K, gamma, beta, bias, (f16_t*)Wp, c, bias_f);
+  if (hk == HK_F16X2) {
+    SG_REQUIRE(K % 8 == 0, "fold_ln_weight: two-plane f16 rows are multiples of 8 elements");
+    hipLaunchKernelGGL(fold_ln_weight_h2_kernel, grid, dim3(256), 0, s, W, N, K, gamma, beta, bias, (h2_t*)Wp, c, bias_f);
+  } else if (hk == HK_F16) hipLaunchKernelGGL(fold_ln_weight_kernel<f16_t>, grid, dim3(256), 0, s, W, N, K, gamma, beta, bias, (f16_t*)Wp, c, bias_f);
   else hipLaunchKernelGGL(fold_ln_weight_kernel<bf16_t>, grid, dim3(256), 0, s, W, N, K, gamma, beta, bias, (bf16_t*)Wp, c, bias_f);
   SG_LAUNCH_CHECK();
   return SG_OK;

@@ -588,6 +588,33 @@ def _ln_chain_ref(A, W1, b1, x, g, be, W2, b2, act):
     return xn.float(), y.float()
 
 
+@pytest.mark.parametrize("M,K1,D,N2,act,mean_shift,outlier", [(1370, 1024, 1024, 3072, 0, 0.0, 20.0), (2055, 4096, 1024, 4096, 1, 0.0, 20.0),
+                                                              (1200, 768, 768, 3072, 2, 3.0, 20.0), (1100, 512, 576, 640, 1, 0.5, 20.0),
+                                                              (1370, 1024, 1024, 3072, 1, 10.0, 300.0)])
+def test_ln_chain_folded_two_plane_is_f32_grade(M, K1, D, N2, act, mean_shift, outlier):
+    """The folded LayerNorm in the exact mode (SG_PREC_F16X2, round 3): the two-plane copy of the raw residual rows out of the producing epilogue,
+    rstd (x.W'^T - mean c) + b' in the consuming one.  Against f64: the folded chain must stay at the error level of the unfolded two-plane chain
+    (explicit LayerNorm pass) -- f32 grade -- including rows whose mean sits many sigma from zero and a massive-activation channel, where the
+    mean * c cancellation is largest; the f32 residual stream is the same GEMM either way."""
+    from clip_decontamination_amd import ops
+    g = lambda *sh, seed, sc=1.0: (torch.from_numpy(np.random.default_rng(seed).standard_normal(sh).astype(np.float32)) * sc).to(DEV)
+    A, W1, b1 = g(M, K1, seed=1), g(D, K1, seed=2, sc=K1 ** -0.5), g(D, seed=3, sc=0.1)
+    x = g(M, D, seed=4) * torch.logspace(-1, 1, M, device=DEV).view(M, 1) + mean_shift
+    x[:, 7] += outlier
+    gamma, beta = 1.0 + 0.3 * g(D, seed=5), 0.2 * g(D, seed=6)
+    W2, b2 = g(N2, D, seed=7, sc=D ** -0.5), g(N2, seed=8, sc=0.1)
+    xf, yf = ops.ln_chain(A, W1, b1, x, gamma, beta, W2, b2, act, "f16x2", fold=True)
+    xu, yu = ops.ln_chain(A, W1, b1, x, gamma, beta, W2, b2, act, "f16x2", fold=False)
+    xr, yr = _ln_chain_ref(A, W1, b1, x, gamma, beta, W2, b2, act)
+    assert torch.equal(xf, xu)
+    ef, eu = (yf - yr).abs(), (yu - yr).abs()
+    scale = yr.abs().max().item()
+    print(f"f16x2 M={M} D={D} N2={N2} shift={mean_shift} outlier={outlier}: folded max {ef.max().item():.3e} mean {ef.mean().item():.3e} | "
+          f"unfolded max {eu.max().item():.3e} mean {eu.mean().item():.3e} (|y| max {scale:.2f})")
+    assert ef.max().item() < 2e-5 * scale                       # the two-plane linear's own bound (test_linear)
+    assert ef.mean().item() < 3.0 * eu.mean().item() + 1e-7 * scale
+
+
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("M,K1,D,N2,act,mean_shift,outlier", [(1370, 1024, 1024, 3072, 0, 0.0, 20.0), (2055, 4096, 1024, 4096, 1, 0.0, 20.0),
                                                               (1200, 768, 768, 3072, 2, 3.0, 20.0), (1024, 512, 512, 512, 0, -1.0, 20.0),
