@@ -187,6 +187,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// The same reductions without the LDS queue: DPP adds inside each row of 16 lanes, then the four row results through v_readlane_b32
+// (every lane gets the same scalar).  For kernels whose whole wave is active; summation order differs from the xor butterfly's.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  const int r = __builtin_bit_cast(int, sum16_dpp(v));
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48)));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
+  const int r = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48))));
+}
+
 // activations of the MLP (reference open_clip/transformer.py:35-38 / nn.GELU)
 // throughput-mode QuickGELU: x * rcp(1 + 2^(-1.702 log2e x)) -- v_exp_f32 + v_rcp_f32 (1 ulp each), inputs end up in bf16 anyway
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x)); }

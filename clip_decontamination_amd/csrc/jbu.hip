@@ -171,8 +171,7 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
       }
     }
     float mx[2] = {fmaxf(val[0][0], val[0][1]), fmaxf(val[1][0], val[1][1])};
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], o, 64)); mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], o, 64)); }
+    mx[0] = wave_max_dpp(mx[0]); mx[1] = wave_max_dpp(mx[1]);   // DPP + v_readlane: no LDS-queue round trips (six ds_bpermute per value before)
     float ex[2][2], s1[2], s2v[2];
     constexpr bool fast = FAST;                                // throughput mode: hardware exp2 / rcp (1 ulp) -- the result is rounded to bf16 anyway
 #pragma unroll
@@ -185,16 +184,14 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
       }
       s1[e] = ex[e][0] + ex[e][1];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1[0] += __shfl_xor(s1[0], o, 64); s1[1] += __shfl_xor(s1[1], o, 64); }
+    s1[0] = wave_sum_dpp(s1[0]); s1[1] = wave_sum_dpp(s1[1]);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float inv = fast ? __builtin_amdgcn_rcpf(s1[e]) : 1.0f / s1[e];
       ex[e][0] = ex[e][0] * inv * sp[0]; ex[e][1] = ex[e][1] * inv * sp[1];
       s2v[e] = ex[e][0] + ex[e][1];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s2v[0] += __shfl_xor(s2v[0], o, 64); s2v[1] += __shfl_xor(s2v[1], o, 64); }
+    s2v[0] = wave_sum_dpp(s2v[0]); s2v[1] = wave_sum_dpp(s2v[1]);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       if (!live[e]) continue;

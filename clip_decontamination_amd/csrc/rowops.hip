@@ -39,7 +39,7 @@ __device__ __forceinline__ void ln_row(float4 (&v)[LN_MAX_VEC], int D, int lane,
 #pragma unroll
   for (int i = 0; i < LN_MAX_VEC; ++i)
     if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  const float mean = wave_sum(s) / (float)D;
+  const float mean = wave_sum_dpp(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAX_VEC; ++i)
@@ -47,7 +47,7 @@ __device__ __forceinline__ void ln_row(float4 (&v)[LN_MAX_VEC], int D, int lane,
       const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (c * c + d * d);
     }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + eps);
 #pragma unroll
   for (int i = 0; i < LN_MAX_VEC; ++i) {
     const int idx = lane + 64 * i;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < LN_MAX_VEC; ++i)
     if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  const float mean = wave_sum(s) / (float)D;
+  const float mean = wave_sum_dpp(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAX_VEC; ++i)
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restr
       const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (c * c + d * d);
     }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + eps);
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAX_VEC; ++i) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restr
       amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
     }
   }
-  amax = wave_max(amax);
+  amax = wave_max_dpp(amax);
   const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
   const float inv = 1.0f / sc;
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(to_f32<T>(xr[c + e])));
   }
-  amax = wave_max(amax);
+  amax = wave_max_dpp(amax);
   const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
   const float inv = 1.0f / sc;
   for (int c = lane * 4; c < D; c += 256)
