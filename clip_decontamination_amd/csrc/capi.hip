@@ -325,7 +325,7 @@ struct Plan {
   float *lse, *lse1, *attn_cls, *attn_diag, *out_last, *y; int32_t *idx_out, *idx_sa; void* refine_scratch;
   float *scores, *probs;
   float *omega, *qnorm, *knorm;
-  float *ln_slice, *ln_rows;                              // folded LayerNorm: slice statistics [R][D/64][2] written by the producing GEMM, (mean, rstd) [R][2]
+  float *ln_slice, *ln_rows;                              // folded LayerNorm: slice statistics [D/64][R][2] (slice-major) written by the producing GEMM, (mean, rstd) [R][2]
   uint8_t* hmx;                                           // SG_PREC_FP8: MX block scales of h8 ([M/128][R][4] E8M0), written by the fc GEMM's epilogue
   uint8_t *x8, *h8; float *sx8, *sh8;                     // SG_PREC_FP8: quantised LN output / GELU output + per-row scales
   float *attn_avg, *sa_tmp, *sa_qk32, *sa_scores, *sa_probs;   // self-attention enhancement, mode='attention'; layer fusion

@@ -258,7 +258,7 @@ struct GemmBf16Args {
   // LayerNorm folded into the two GEMMs either side of it (persistent kernel only, batch 1; capi.hip std_block).  LN(x).W^T + b =
   // rstd (x.W'^T - mean c) + b' with W' = gamma o W, c[n] = sum_k W'[n][k], b' = b + W.beta, so the normalisation never runs as a pass:
   //   producer (f32 C, with or without residual): copy16 / ld16 = a 2-byte copy of the finished rows (the next GEMM's A operand),
-  //     row_stats [M][N/64][2] = (sum, centred sum of squares) of every 64-column slice of a finished row
+  //     row_stats [N/64][M][2] = (sum, centred sum of squares) of every 64-column slice of a finished row (slice-major: full-line stores)
   //   consumer: ln_stats [M][2] = (mean, rstd) per row, ln_c = c; bias = b'
   void* copy16; int64_t ld16; float* row_stats;
   const float* ln_stats; const float* ln_c;

@@ -868,7 +868,7 @@ static thread_local int g_gemm_order = -1;                 // tuning (sg_set_gem
 // SPLIT (two-plane f16, MODE 0 / SPEC 0 only): a "2-byte" C is written as [8 hi | 8 lo] storage groups; exact activations.
 template <int MI, int NI, bool F16, int MODE = 0, int SPEC = 0, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const GemmBf16Args& a, int act_rt, int c_bf16_rt, int z, int row0,
-                                                int col0, float* patch, int lane) {
+                                                int col0, float* patch, int lane, float* statbuf = nullptr) {
   static_assert(!SPLIT || SPEC != 5, "two-plane f16: no row-dot form");
   constexpr bool LN = MODE == 1, PROD = MODE == 2;
   // SPEC > 0: activation (SPEC - 1), output type (2-byte in MODE 0 / 1, f32 in MODE 2) and the presence of a residual (MODE 2 only) are
@@ -1055,9 +1055,21 @@ __device__ __forceinline__ void epilogue_store8(f32x4 (&acc)[MI][NI], const Gemm
           const float e0 = y0.x - mu, e1 = y0.y - mu, e2 = y0.z - mu, e3 = y0.w - mu, e4 = y1.x - mu, e5 = y1.y - mu, e6 = y1.z - mu, e7 = y1.w - mu;
           float sq = ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7));
           sq = sum8_dpp(sq);
-          if ((lane & 7) == 0 && m8 < a.M && col0 < a.N)      // col0 >= N (N % 256 != 0): this wave's slice does not exist -- its slot would be row m8+1's
-            *reinterpret_cast<float2*>(a.row_stats + ((int64_t)m8 * (a.N >> 6) + (col0 >> 6)) * 2) = make_float2(sm, sq);
+          // the 8 row leaders park (sum, centred squares) of rows t * 8 + r8 of this wave's 16 * MI rows in LDS; written out once, below
+          if ((lane & 7) == 0) *reinterpret_cast<float2*>(statbuf + 2 * (t * 8 + r8)) = make_float2(sm, sq);
         }
+      }
+    }
+  }
+  if constexpr (PROD) {
+    // slice statistics, SLICE-MAJOR [N / 64][M][2]: the wave's 16 * MI rows of its one slice are contiguous, so they leave as full lines
+    // (round 3; as [M][N / 64][2] every row leader wrote 8 bytes into a line of its own -- 2.6 M partial-line writes per launch at the
+    // bench shape, which cost the two-plane producer 0.2 ms per launch)
+    if (col0 < a.N) {                                        // col0 >= N (N % 256 != 0): this wave's slice does not exist
+#pragma unroll
+      for (int rr = lane; rr < 16 * MI; rr += 64) {
+        const int m = row0 + rr;
+        if (m < a.M) *reinterpret_cast<float2*>(a.row_stats + ((int64_t)(col0 >> 6) * a.M + m) * 2) = *reinterpret_cast<const float2*>(statbuf + 2 * rr);
       }
     }
   }
@@ -1232,7 +1244,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist(GemmBf16Args a, int act
 #if SG_PS_ABL == 4
       if (acc[0][0][0] == 1234.5678f)                                                       // keep the accumulators live, store (almost) nothing
 #endif
-      epilogue_store8<8, 4, F16, EPI, SPEC>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane);
+      epilogue_store8<8, 4, F16, EPI, SPEC>(acc, a, act, c_bf16, z, cur.m0 + 128 * g, cur.n0 + 64 * wi, patch, lane,
+                                            reinterpret_cast<float*>(lds + ((s - 1) & 3) * TILE_B) + 8 * 576 + wave * 256);   // 1 KiB per wave behind the 8 patches
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);
@@ -1673,7 +1686,7 @@ __global__ __launch_bounds__(512) void gemm_h2_persist(GemmBf16Args a, int act, 
     if (g == 0) SG_H2_SYNC();                                            // align: every read of this tile's last K step has retired
     {
       float* pbase = reinterpret_cast<float*>(ldsA + ((s - 1) & 1) * SLOT);    // the consumed A slot: 8 patches of 8 rows x 68 floats (+pad)
-      epilogue_store8<8, 4, true, EPI, SPEC, true>(acc, a, act, c_bf16, 0, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, lane);
+      epilogue_store8<8, 4, true, EPI, SPEC, true>(acc, a, act, c_bf16, 0, cur.m0 + 128 * g, cur.n0 + 64 * wi, pbase + wave * 576, lane, pbase + 8 * 576 + wave * 256);
     }
     cur = nxt; cur_end += nt;
     if (j + 2 < my_tiles) nxt = make_src(j + 2);

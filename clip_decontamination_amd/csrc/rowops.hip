@@ -344,27 +344,22 @@ int pack_rows(const float* src, int64_t rows, int cols, int64_t ld_src, void* ds
 }
 
 // ---- LayerNorm folded into the neighbouring GEMMs -----------------------------------------------------------------------------------
-// Chan's pairwise combination of the per-slice (sum, centred sum of squares): exact to f32 rounding whatever the mean is.
-// 16 lanes per row (one 64-column slice each when D = 1024; they stride over more), coalesced 8-byte loads.
+// Chan's combination of the per-slice (sum, centred sum of squares): exact to f32 rounding whatever the mean is.
+// st is slice-major [S][rows][2] (what the producing epilogue writes as full lines): one thread per row, coalesced 8-byte loads.
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ st, int64_t rows, int S, float eps, float* __restrict__ out) {
-  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int l = threadIdx.x & 15;
-  const bool live = r < rows;
-  const float2* p = reinterpret_cast<const float2*>(st) + (live ? r : 0) * S;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(st) + r;
   float tot = 0.f;
-  for (int i = l; i < S; i += 16) tot += p[i].x;
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) tot += __shfl_xor(tot, o, 64);
+  for (int i = 0; i < S; ++i) tot += p[(int64_t)i * rows].x;
   const float mean = tot / (float)(S * 64);
   float m2 = 0.f;
-  for (int i = l; i < S; i += 16) { const float d = p[i].x * (1.0f / 64.0f) - mean; m2 += p[i].y + 64.0f * d * d; }
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o, 64);
-  if (live && l == 0) reinterpret_cast<float2*>(out)[r] = make_float2(mean, 1.0f / sqrtf(m2 / (float)(S * 64) + eps));
+  for (int i = 0; i < S; ++i) { const float2 v = p[(int64_t)i * rows]; const float d = v.x * (1.0f / 64.0f) - mean; m2 += v.y + 64.0f * d * d; }
+  reinterpret_cast<float2*>(out)[r] = make_float2(mean, 1.0f / sqrtf(m2 / (float)(S * 64) + eps));
 }
 int ln_stats_finalize(const float* slice_stats, int64_t rows, int D, float eps, float* mean_rstd, hipStream_t s) {
   SG_REQUIRE(D % 64 == 0 && rows > 0, "ln_stats_finalize: D=%d must be a multiple of 64", D);
-  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, s, slice_stats, rows, D / 64, eps, mean_rstd);
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, s, slice_stats, rows, D / 64, eps, mean_rstd);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }
