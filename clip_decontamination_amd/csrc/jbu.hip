@@ -1117,6 +1117,111 @@ __global__ __launch_bounds__(256, 2) void jbu_pixel_logits_kernel(const XT* __re
       }
   }
 }
+
+// The same product on the matrix pipe (round 3; Q <= 16, C % 32 == 0): logits = x . Geff is a [pixels, C] x [C, 16] GEMM whose A operand is
+// the bf16 rows as they lie in HBM.  Geff is held as TWO bf16 planes (hi + lo = 16 significant bits, well below the 8 bits of x) in LDS,
+// [16 q][C] each, so a B fragment is one ds_read_b128; a wave owns 64 consecutive pixels (4 row tiles of v_mfma_f32_16x16x32_bf16) per
+// round and PLM_ROUNDS rounds, the A fragments come straight from global memory (16 B per lane: row = lane % 16, 8 consecutive channels), one
+// k-step ahead.  |x|^2 rides along on the vector pipe from the same fragments.  The lane-per-pixel VALU form above ran at a third of the
+// f32 vector peak (3.1 ms per 8 tiles of 592 x 592 at C = 768: 69 GFLOP of f32 FMAs); this one is bound by the 4.3 GB read of x.
+constexpr int PLM_ROUNDS = 4;
+__global__ __launch_bounds__(256, 2) void jbu_pixel_logits_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ rowdot, int slots,
+                                                                       const float* __restrict__ geff, const float* __restrict__ g0,
+                                                                       const float* __restrict__ clsl, float lambda, int64_t pixels, int64_t P, int C,
+                                                                       int Q, float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) char plm_sm[];
+  bf16_t* sGh = reinterpret_cast<bf16_t*>(plm_sm);                        // [16][C + 8]  (+8: rows 16 bytes apart in the banks)
+  const int ldg = C + 8;
+  bf16_t* sGl = sGh + 16 * ldg;
+  float* sN = reinterpret_cast<float*>(sGl + 16 * ldg);                   // [4 waves][64] 1 / |out| of the wave's pixels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 16 * C; i += 256) {
+    const int q = i / C, c = i % C;
+    const float v = q < Q ? geff[c * JBU_QMAX + q] : 0.f;
+    const bf16_t hi = f2bf(v);
+    sGh[q * ldg + c] = hi;
+    sGl[q * ldg + c] = f2bf(v - bf2f(hi));
+  }
+  __syncthreads();
+  const int r = lane & 15, g = lane >> 4;
+  float* myN = sN + wave * 64;
+  for (int round = 0; round < PLM_ROUNDS; ++round) {
+    const int64_t pix0 = (((int64_t)blockIdx.x * PLM_ROUNDS + round) * 4 + wave) * 64;
+    if (pix0 >= pixels) return;                                           // wave-uniform; no barrier below
+    const bf16_t* xr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int64_t pr = pix0 + t * 16 + r;
+      pr = pr < pixels ? pr : pixels - 1;
+      xr[t] = x + pr * C + 8 * g;
+    }
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float nx[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 a_cur[4], a_nxt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_cur[t] = *reinterpret_cast<const bf16x8*>(xr[t]);
+    const int nk = C / 32;
+    for (int ks = 0; ks < nk; ++ks) {
+      const int kn = ks + 1 < nk ? ks + 1 : ks;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a_nxt[t] = *reinterpret_cast<const bf16x8*>(xr[t] + 32 * kn);
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sGh + r * ldg + 32 * ks + 8 * g);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sGl + r * ldg + 32 * ks + 8 * g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t] = mfma_16x16x32<false>(a_cur[t], bh, acc[t]);               // D[pixel i][query j]: lane = j + 16 (i / 4), 4 consecutive pixels
+        acc[t] = mfma_16x16x32<false>(a_cur[t], bl, acc[t]);
+        const uint4 raw = __builtin_bit_cast(uint4, a_cur[t]);
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+          nx[t] = __builtin_fmaf(lo, lo, nx[t]); nx[t] = __builtin_fmaf(hi, hi, nx[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a_cur[t] = a_nxt[t];
+    }
+    // |x|^2 of pixel (t, r): the four 8-channel slices of every k-step sit in lanes r, r + 16, r + 32, r + 48
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { nx[t] += __shfl_xor(nx[t], 16, 64); nx[t] += __shfl_xor(nx[t], 32, 64); }
+    if (g == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int64_t pix = pix0 + t * 16 + r;
+        pix = pix < pixels ? pix : pixels - 1;
+        float n2 = nx[t];
+        for (int sidx = 0; sidx < slots; ++sidx) n2 += rowdot[pix * slots + sidx];      // fixed order: deterministic
+        myN[t * 16 + r] = 1.0f / sqrtf(n2);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // lane holds pixels pix0 + 16 t + 4 g .. + 3 of query r
+    if (r < Q) {
+      const float g0q = g0[r];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int64_t pix = pix0 + t * 16 + 4 * g;
+        if (pix >= pixels) continue;
+        const float4 inv = *reinterpret_cast<const float4*>(myN + t * 16 + 4 * g);
+        const int64_t b = pix / P, pp = pix % P;
+        float4 o = make_float4((acc[t][0] + g0q) * inv.x, (acc[t][1] + g0q) * inv.y, (acc[t][2] + g0q) * inv.z, (acc[t][3] + g0q) * inv.w);
+        if (clsl) { const float cv = lambda * clsl[b * JBU_QMAX + r]; o.x += cv; o.y += cv; o.z += cv; o.w += cv; }
+        float* dst = logits + (b * Q + r) * P + pp;
+        if (pp + 3 < P && pix + 3 < pixels && (P & 3) == 0) *reinterpret_cast<float4*>(dst) = o;   // P % 4 == 0: the four pixels share the image and the store is aligned
+        else {
+          const float ov[4] = {o.x, o.y, o.z, o.w};
+          for (int e = 0; e < 4; ++e) {
+            const int64_t pe = pix + e;
+            if (pe < pixels) logits[((pe / P) * Q + r) * P + pe % P] = ov[e] + ((clsl && pe / P != b) ? lambda * (clsl[(pe / P) * JBU_QMAX + r] - clsl[b * JBU_QMAX + r]) : 0.f);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                                      // myN is rewritten in the next round
+  }
+}
 }  // namespace sg
 
 // sg_jbu_logits replaces, for a batch of tiles,  feats = upsampler(tokens, img) -> feats /= |feats| -> feats @ T^T (+ lambda * cls_logits)
@@ -1157,7 +1262,12 @@ extern "C" int sg_jbu_logits(sg_jbu* j, const float* source, const float* guidan
     hipLaunchKernelGGL((jbu_pixel_logits_kernel<QP, bf16_t>), dim3(grid), dim3(256), lds, s, x16, p.rowdot, slots, p.geff, p.g0,  \
                        use_cls ? p.clsl : nullptr, cls_token_lambda, pixels, P, C, Q, logits);                                 \
   } while (0)
-  if (Q <= 8) SG_JBU_PIX(8); else if (Q <= 16) SG_JBU_PIX(16); else SG_JBU_PIX(32);
+  if (Q <= 16 && C % 32 == 0) {                              // matrix-pipe form
+    const size_t lds = (size_t)2 * 16 * (C + 8) * sizeof(bf16_t) + 4 * 64 * sizeof(float);
+    SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_pixel_logits_mfma_kernel), lds));
+    hipLaunchKernelGGL(jbu_pixel_logits_mfma_kernel, dim3((unsigned)cdiv(pixels, 4 * 64 * PLM_ROUNDS)), dim3(256), lds, s, x16, p.rowdot, slots, p.geff, p.g0,
+                       use_cls ? p.clsl : nullptr, cls_token_lambda, pixels, P, C, Q, logits);
+  } else if (Q <= 8) SG_JBU_PIX(8); else if (Q <= 16) SG_JBU_PIX(16); else SG_JBU_PIX(32);
 #undef SG_JBU_PIX
   SG_LAUNCH_CHECK();
   return SG_OK;
