@@ -214,6 +214,135 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
   }
 }
 
+// Throughput-mode form of the same kernel with the key dot products on the matrix pipe (round 3).  In the form above every lane reads
+// its tap's 32-dimensional key vector from LDS for every pixel (24 ds_read_b128 per pixel and wave: the kernel was LDS-bound).  Here the
+// window's key vectors are staged as f16 (11 bits against the bf16 the weights end in), and for one row of 8 pixels a wave computes
+//     S[pos][pixel] = key[pos] . key[centre(pixel)]      pos = the D x WT window positions the row's taps can touch (198 at r = 5)
+// as NT tiles of ONE v_mfma_f32_16x16x32_f16 each (K = KEY_DIM = 32), parks S as [8 pixels][positions] f32 in LDS and then walks the pixels
+// with the taps on the lanes as before -- one ds_read_b32 per tap instead of eight ds_read_b128.  Same softmax / normalisation arithmetic,
+// same outputs (X f32 rows, X16 bf16 operand rows).
+template <int R>
+struct JkmCfg {
+  static constexpr int D = 2 * R + 1, D2 = D * D, WT = AC_T + 2 * R, NWIN = WT * WT;
+  static constexpr int NROWPOS = (D - 1) * WT + D + 7;                 // window positions (relative to the row's first) the taps of a pixel row touch
+  static constexpr int NT = (NROWPOS + 15) / 16, SP = NT * 16, LDS_S = SP + 4;
+  static constexpr int KLD = KEY_DIM + 8;                               // f16 key row stride (80 bytes)
+  static constexpr size_t LDS = (size_t)NWIN * KLD * 2 + (size_t)4 * 8 * LDS_S * 4;
+};
+template <int R>
+__global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int H, int W,
+                                                                 const float* __restrict__ range_temp, const float* __restrict__ sigma,
+                                                                 float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16) {
+  using J = JkmCfg<R>;
+  constexpr int D = J::D, D2 = J::D2, LDX = D2 + 3, WT = J::WT, NWIN = J::NWIN, NT = J::NT, LDS_S = J::LDS_S, KLD = J::KLD;
+  static_assert(KEY_DIM == 32, "one MFMA k-step per product");
+  extern __shared__ __attribute__((aligned(16))) char jkm_sm[];
+  uint16_t* win = reinterpret_cast<uint16_t*>(jkm_sm);                   // [NWIN][KLD] f16
+  float* sS = reinterpret_cast<float*>(jkm_sm + (size_t)NWIN * KLD * 2);  // [4 waves][8][LDS_S]
+  const int tiles_x = (W + AC_T - 1) / AC_T;
+  const int ty0 = (blockIdx.x / tiles_x) * AC_T, tx0 = (blockIdx.x % tiles_x) * AC_T;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t img = (int64_t)b * H * W;
+  for (int i0 = 0; i0 < NWIN * (KEY_DIM / 4); i0 += 256 * 4) {           // four 16-byte pieces per thread in flight per round
+    float4 pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + tid + u * 256;
+      i = i < NWIN * (KEY_DIM / 4) ? i : NWIN * (KEY_DIM / 4) - 1;
+      const int pos = i / (KEY_DIM / 4), q = i % (KEY_DIM / 4);
+      int sy = ty0 + pos / WT - R, sx = tx0 + pos % WT - R;
+      sy = sy > H - 1 + R ? H - 1 + R : sy; sx = sx > W - 1 + R ? W - 1 + R : sx;    // ragged last tile: stay inside the padded image
+      sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
+      pv[u] = *reinterpret_cast<const float4*>(proj + (img + (int64_t)sy * W + sx) * KEY_DIM + 4 * q);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + tid + u * 256;
+      if (i < NWIN * (KEY_DIM / 4))
+        *reinterpret_cast<uint2*>(win + (i / (KEY_DIM / 4)) * KLD + 4 * (i % (KEY_DIM / 4))) = make_uint2(pack_h2(pv[u].x, pv[u].y), pack_h2(pv[u].z, pv[u].w));
+    }
+  }
+  __syncthreads();
+  const float temp = fminf(fmaxf(expf(range_temp[0]), 1e-4f), 1e4f);
+  const float sg = sigma[0];
+  const float step = 2.0f / (float)(D - 1);
+  int toff[2]; float sp[2]; bool tv[2];                                   // tap geometry of this lane (two taps per lane), independent of the pixel
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int t = lane + 64 * s2;
+    tv[s2] = t < D2;
+    const int ti = tv[s2] ? t / D : 0, tj = tv[s2] ? t % D : 0;
+    toff[s2] = ti * WT + tj;
+    const float fi = -1.0f + (float)ti * step, fj = -1.0f + (float)tj * step;
+    sp[s2] = tv[s2] ? expf(-(fi * fi + fj * fj) / (2.0f * sg * sg)) : 0.f;
+  }
+  float* myS = sS + wave * 8 * LDS_S;
+  const int li = lane & 15, lg = lane >> 4;
+  for (int round = 0; round < 2; ++round) {
+    const int py = wave * 2 + round;
+    // ---- S[pos][pixel] for the 8 pixels of row py ----
+    {
+      const bf16x8 cfrag = *reinterpret_cast<const bf16x8*>(win + ((py + R) * WT + (li & 7) + R) * KLD + 8 * lg);   // second port: row = pixel (8..15 repeat 0..7)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int pos = py * WT + nt * 16 + li;
+        pos = pos < NWIN ? pos : NWIN - 1;
+        const bf16x8 pfrag = *reinterpret_cast<const bf16x8*>(win + pos * KLD + 8 * lg);                             // first port: row = window position
+        const f32x4 acc = mfma_16x16x32<true>(pfrag, cfrag, (f32x4){0.f, 0.f, 0.f, 0.f});   // lane: pixel li, positions nt*16 + 4 lg .. + 3
+        if (li < 8) *reinterpret_cast<float4*>(myS + li * LDS_S + nt * 16 + 4 * lg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                // a wave's LDS instructions execute in order: ordering only
+    __builtin_amdgcn_wave_barrier();
+    // ---- the pixels of the row, two at a time (px, px + 4), taps on the lanes ----
+    for (int pp = 0; pp < 4; ++pp) {
+      float val[2][2]; int64_t pixi[2]; bool live[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int px = pp + 4 * e;
+        const int y = ty0 + py, x = tx0 + px;
+        live[e] = y < H && x < W;                                         // wave-uniform
+        pixi[e] = img + (int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) val[e][s2] = tv[s2] ? temp * myS[px * LDS_S + px + toff[s2]] : -INFINITY;
+      }
+      float mx[2] = {fmaxf(val[0][0], val[0][1]), fmaxf(val[1][0], val[1][1])};
+      mx[0] = wave_max_dpp(mx[0]); mx[1] = wave_max_dpp(mx[1]);
+      float ex[2][2], s1[2], s2v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        ex[e][0] = __builtin_amdgcn_exp2f((val[e][0] - mx[e]) * 1.4426950408889634f);
+        ex[e][1] = __builtin_amdgcn_exp2f((val[e][1] - mx[e]) * 1.4426950408889634f);
+        s1[e] = ex[e][0] + ex[e][1];
+      }
+      s1[0] = wave_sum_dpp(s1[0]); s1[1] = wave_sum_dpp(s1[1]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float inv = __builtin_amdgcn_rcpf(s1[e]);
+        ex[e][0] = ex[e][0] * inv * sp[0]; ex[e][1] = ex[e][1] * inv * sp[1];
+        s2v[e] = ex[e][0] + ex[e][1];
+      }
+      s2v[0] = wave_sum_dpp(s2v[0]); s2v[1] = wave_sum_dpp(s2v[1]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!live[e]) continue;
+        const float rn = __builtin_amdgcn_rcpf(fmaxf(s2v[e], 1e-7f));
+        const float k0 = ex[e][0] * rn, k1 = ex[e][1] * rn;
+        const int64_t pix = pixi[e];
+        float* xr = X + pix * LDX;
+        if (lane < D2) xr[lane] = k0;
+        if (lane + 64 < D2) xr[lane + 64] = k1;
+        if (lane < 3) xr[D2 + lane] = gs[pix * 3 + lane];
+        bf16_t* x16 = X16 + pix * ldx16;                                  // [taps | guidance | zero padding] as the bf16 A operand of the fixup GEMM
+        if (lane < ldx16) x16[lane] = f2bf(lane < D2 ? k0 : (lane < D2 + 3 ? gs[pix * 3 + (lane - D2)] : 0.f));
+        const int t2 = lane + 64;
+        if (t2 < ldx16) x16[t2] = f2bf(t2 < D2 ? k1 : (t2 < D2 + 3 ? gs[pix * 3 + (t2 - D2)] : 0.f));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                                      // S is rewritten by the next round
+  }
+}
+
 // ---- bicubic 2x (torch.nn.Upsample(size, mode='bicubic', align_corners=False), A = -0.75) on [B,h,w,C] -> [B,oh,ow,C] ----------
 __device__ __forceinline__ float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
@@ -891,9 +1020,20 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
       using JK = void (*)(const float*, const float*, int, int, int, const float*, const float*, float*, bf16_t*, int);
       const JK jk = fast ? (r == 5 ? jbu_kernel_tiled_kernel<5, true> : r == 3 ? jbu_kernel_tiled_kernel<3, true> : jbu_kernel_tiled_kernel<0, true>)
                          : jbu_kernel_tiled_kernel<0, false>;
+      if (fast && (r == 5 || r == 3)) {                     // key dot products on the matrix pipe
+        const dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
+        if (r == 5) {
+          SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_mfma_kernel<5>), JkmCfg<5>::LDS));
+          hipLaunchKernelGGL(jbu_kernel_mfma_kernel<5>, grid, dim3(256), JkmCfg<5>::LDS, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1);
+        } else {
+          SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_mfma_kernel<3>), JkmCfg<3>::LDS));
+          hipLaunchKernelGGL(jbu_kernel_mfma_kernel<3>, grid, dim3(256), JkmCfg<3>::LDS, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1);
+        }
+      } else {
       SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jk), 64 * 1024));
       hipLaunchKernelGGL(jk, dim3((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B), dim3(256), lds, s, p.proj, p.gs, oh,
                          ow, r, S.range_temp, S.sigma, p.X, fast ? p.X16 : nullptr, KP1);
+      }
       SG_LAUNCH_CHECK();
     }
     SG_REQUIRE(pixels < (1ll << 31), "sg_jbu_upsample: too many pixels");
