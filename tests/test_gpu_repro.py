@@ -111,3 +111,73 @@ def test_jbu_logits_tail_is_reproducible():
         torch.cuda.synchronize()
         outs.append(lg)
     _same(outs, "JBU fused logits tail")
+
+
+# ---- the drop-in classes end to end: slide -> logits -> labels, twice -------------------------------------------------------------------
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
+
+def _names(f):
+    return __import__("os").path.join(ROOT, "configs", f)
+
+
+def _build(cls_name, vit, name_file, precision, **kw):
+    import segmentor, segearth_segmentor
+    cls = segmentor.SegmentorEx if cls_name == "SegmentorEx" else segearth_segmentor.Segmentor
+    cfg = Wt.vit_config(vit)
+    words, _ = segmentor.get_cls_idx(_names(name_file))
+    text = torch.from_numpy(Wt.make_text_features(len(words), cfg.embed_dim))
+    return cls(clip_type="CLIP", vit_type=vit, name_path=_names(name_file), device=torch.device("cuda:0"), precision=precision,
+               synthetic_ok=True, text_features=text, **kw)
+
+
+def _scene(H, W, seed):
+    u8 = Wt.make_tiles_u8(1, max(H, W), seed=seed, smooth=True)[:, :H, :W]
+    return torch.from_numpy(Wt.normalize_tiles(u8))
+
+
+SIM = dict(similarity_weight=1.0, temperature=1.0, add_self_similarity=True)
+E2E = {
+    # the shipped refiner stack of the headline (similarity map + outlier suppression, 'Experimental' last block), 5 x 5 tiles of 224
+    "b16_refiners": ("SegmentorEx", "ViT-B/16", "cls_potsdam.txt", dict(model_type="Experimental", global_debias_factor=0.2, apply_similarity_enhancement=True,
+                     similarity_enhancement_cfg=SIM, apply_outlier_suppression=True, outlier_suppression_cfg=dict(top_k=30), prob_thd=0.1, bg_idx=5,
+                     slide_crop=224, slide_stride=112), (672, 672)),
+    # GEM dual stream + outlier suppression in one forward (BASELINE configs[2])
+    "l14_gem_outlier": ("Segmentor", "ViT-L/14", "cls_loveda.txt", dict(model_type="GEM", cls_token_lambda=0.0, slide_crop=224, slide_stride=112,
+                        apply_sim_feat_up=False, prob_thd=0.3, apply_outlier_suppression=True, outlier_suppression_cfg=dict(top_k=30)), (448, 560)),
+    # cross-tile fusion + Cluster-Then-Debias
+    "b16_ctf_ctd": ("SegmentorEx", "ViT-B/16", "cls_xBD.txt", dict(model_type="SegEarth", global_debias_factor=0.2, prob_thd=0.0, slide_crop=224, slide_stride=224,
+                    apply_sim_feat_up=False, apply_ctd=True, cross_tile_fusion_cfg=dict(fusion_mode="weighted", cache_boundary_width=2, fusion_strength=0.3)), (672, 672)),
+    # SimFeatUp JBU to per-pixel logits (fused tail in the throughput modes)
+    "b16_jbu": ("SegmentorEx", "ViT-B/16", "cls_isaid.txt", dict(model_type="SegEarth", global_debias_factor=0.2, slide_crop=224, slide_stride=112,
+                apply_sim_feat_up=True, sim_feat_up_cfg=dict(model_name="jbu_one", model_path=None)), (448, 448)),
+}
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16x2"])
+@pytest.mark.parametrize("case", list(E2E))
+def test_segmentor_end_to_end_is_reproducible(case, prec):
+    cls_name, vit, name_file, kw, (H, W) = E2E[case]
+    seg = _build(cls_name, vit, name_file, prec, **kw)
+    img = _scene(H, W, 31).cuda()
+    outs, labs = [], []
+    for _ in range(3):
+        lg = seg.forward_slide(img, [dict(ori_shape=(H, W))], kw["slide_stride"], kw["slide_crop"])
+        torch.cuda.synchronize()
+        outs.append(lg.clone())
+        labs.append(seg.postprocess_result(lg, None).clone())
+    _same(outs, f"{case} {prec} logits")
+    _same(labs, f"{case} {prec} labels")
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16x2", "f32"])
+def test_text_tower_is_reproducible(prec):
+    from clip_decontamination_amd.engine import HipTextTower
+    tc = Wt.TEXT_CONFIGS["ViT-B-16"]
+    tt = HipTextTower(tc, Wt.make_text_weights(tc, seed=0), precision=prec, device="cuda:0")
+    ids = torch.from_numpy(Wt.make_token_ids(tc, 160))
+    outs = []
+    for _ in range(RUNS):
+        outs.append(tt.encode_text(ids).clone())
+        torch.cuda.synchronize()
+    _same(outs, f"text tower {prec}")
