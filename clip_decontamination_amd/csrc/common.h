@@ -240,6 +240,7 @@ struct GemmBf16Args {
   const bf16_t* W; int64_t ldw; int64_t strideW;
   const float* bias;                                  // [N] or null
   const float* residual; int64_t ldr;                 // f32 [M,N] or null (batch stride = strideC)
+  int res_half;                                       // the residual is 2-byte in the operands' type (ldr in elements): 2-byte outputs of the small-tile kernels only
   void* C; int64_t ldc; int64_t strideC; int c_is_bf16;   // C: 0 = f32, 1 = the operands' 2-byte type (bf16, or f16 when `f16` is set)
   int f16;                                            // operands (and a 2-byte C) are IEEE f16 instead of bf16: SG_PREC_F16
   int h2;                                             // SG_PREC_F16X2: A, W (and C when c_is_bf16) are two-plane f16 (h2_t: 4 bytes per element, lda / ldw / ldc /

@@ -226,8 +226,19 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[MI][NI], const GemmB
             if ((lane & 3) == 0) { const int nb = n >> 5; a.c_mx_scale[((int64_t)(nb >> 2) * a.M + m) * 4 + (nb & 3)] = (uint8_t)E; }
           }
         } else if (r < 16 && m < a.M && n < a.N) {
-          const float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
-          const float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
+          float4 x0 = *reinterpret_cast<const float4*>(patch + r * LDP + cq);
+          float4 x1 = *reinterpret_cast<const float4*>(patch + r * LDP + cq + 4);
+          if (SPEC == 0 && !SPLIT && res && a.res_half) {  // 2-byte residual in the operands' type (JBU fixup chain in f16)
+            const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.residual) + (int64_t)z * a.strideC + (int64_t)m * a.ldr + n);
+            const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+            float rv[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (F16) { rv[2 * e] = h2f(f16_t{(uint16_t)(w[e] & 0xffffu)}); rv[2 * e + 1] = h2f(f16_t{(uint16_t)(w[e] >> 16)}); }
+              else { rv[2 * e] = __uint_as_float(w[e] << 16); rv[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+            }
+            x0.x += rv[0]; x0.y += rv[1]; x0.z += rv[2]; x0.w += rv[3]; x1.x += rv[4]; x1.y += rv[5]; x1.z += rv[6]; x1.w += rv[7];
+          }
           if constexpr (SPLIT) {
             const float v8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             store_h2x8(reinterpret_cast<h2_t*>(a.C) + (int64_t)z * a.strideC + (int64_t)m * a.ldc + n, v8);
@@ -1898,7 +1909,11 @@ int gemm_bf16(const GemmBf16Args& a, hipStream_t s) {
   int cfg = g_gemm_config;
   if (cfg == 33 || cfg == 34 || cfg == 36 || cfg == 37) cfg = -1;                    // tuning codes read by capi.hip (MX hand-off / LayerNorm folding off), not tile configurations
   if (a.rowdot || ln_fold) cfg = 30;
-  if (cfg < 0 || a.f16) cfg = (a.rowdot || ln_fold || (a.M >= 1024 && a.N >= 512 && !(few_tiles(a.M, a.N) && a.batch == 1))) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
+  if (a.res_half) {                                          // 2-byte residual: the small-tile kernel's run-time epilogue only
+    SG_REQUIRE(vec && a.residual && a.c_is_bf16 && !a.rowdot && !ln_fold && a.ldr % 8 == 0, "gemm_bf16: res_half needs a 2-byte C, N %% 8 == 0 and ldr %% 8 == 0");
+    cfg = 4;
+  }
+  if (!a.res_half && (cfg < 0 || a.f16)) cfg = (a.rowdot || ln_fold || (a.M >= 1024 && a.N >= 512 && !(few_tiles(a.M, a.N) && a.batch == 1))) ? 30 : 4;  // large: persistent ping-pong; small: 128x128 tiles (more workgroups); f16 operands: these two only
   if (cfg > 0) {
     const int pcat = (cfg == 30 && vec && a.K / 32 >= 4) ? (a.ln_stats ? PROF_GEMM_PERSIST_LN_CONSUMER : a.copy16 ? PROF_GEMM_PERSIST_LN_PRODUCER : PROF_GEMM_PERSIST)
                                                          : PROF_GEMM_BF16;

@@ -232,7 +232,7 @@ struct JkmCfg {
 template <int R>
 __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int H, int W,
                                                                  const float* __restrict__ range_temp, const float* __restrict__ sigma,
-                                                                 float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16) {
+                                                                 float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16, int half_only) {
   using J = JkmCfg<R>;
   constexpr int D = J::D, D2 = J::D2, LDX = D2 + 3, WT = J::WT, NWIN = J::NWIN, NT = J::NT, LDS_S = J::LDS_S, KLD = J::KLD;
   static_assert(KEY_DIM == 32, "one MFMA k-step per product");
@@ -329,14 +329,23 @@ __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __
         const float rn = __builtin_amdgcn_rcpf(fmaxf(s2v[e], 1e-7f));
         const float k0 = ex[e][0] * rn, k1 = ex[e][1] * rn;
         const int64_t pix = pixi[e];
-        float* xr = X + pix * LDX;
-        if (lane < D2) xr[lane] = k0;
-        if (lane + 64 < D2) xr[lane + 64] = k1;
-        if (lane < 3) xr[D2 + lane] = gs[pix * 3 + lane];
-        bf16_t* x16 = X16 + pix * ldx16;                                  // [taps | guidance | zero padding] as the bf16 A operand of the fixup GEMM
-        if (lane < ldx16) x16[lane] = f2bf(lane < D2 ? k0 : (lane < D2 + 3 ? gs[pix * 3 + (lane - D2)] : 0.f));
+        // [taps | guidance | zero padding]: the 2-byte A operand of the fixup GEMM.  half_only (the all-f16 fixup chain of the low-res path): f16
+        // rows that also serve as that chain's residual, and no f32 rows at all (752 -> 256 bytes written per pixel)
+        const float v0 = lane < D2 ? k0 : (lane < D2 + 3 ? gs[pix * 3 + (lane - D2)] : 0.f);
         const int t2 = lane + 64;
-        if (t2 < ldx16) x16[t2] = f2bf(t2 < D2 ? k1 : (t2 < D2 + 3 ? gs[pix * 3 + (t2 - D2)] : 0.f));
+        const float v1 = t2 < D2 ? k1 : (t2 < D2 + 3 ? gs[pix * 3 + (t2 - D2)] : 0.f);
+        bf16_t* x16 = X16 + pix * ldx16;
+        if (half_only) {
+          if (lane < ldx16) x16[lane] = f2h(v0).bits;
+          if (t2 < ldx16) x16[t2] = f2h(v1).bits;
+        } else {
+          float* xr = X + pix * LDX;
+          if (lane < D2) xr[lane] = k0;
+          if (lane + 64 < D2) xr[lane + 64] = k1;
+          if (lane < 3) xr[D2 + lane] = gs[pix * 3 + lane];
+          if (lane < ldx16) x16[lane] = f2bf(v0);
+          if (t2 < ldx16) x16[t2] = f2bf(v1);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();                                      // S is rewritten by the next round
@@ -583,7 +592,7 @@ __device__ __forceinline__ float dot2_f16(uint32_t a, uint32_t b, float acc) {
 
 template <int R>
 __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* __restrict__ src, const float* __restrict__ Kf, int ldk, int h, int w,
-                                                                 int C, float* __restrict__ out, bf16_t* __restrict__ out16) {
+                                                                 int C, float* __restrict__ out, bf16_t* __restrict__ out16, int kf_half) {
   using L = LowCfg<R>;
   constexpr int D = L::D, D2 = L::D2, DPH = L::DPH, DP = L::DP, LW = L::LW, LWP = L::LWP, KP = L::KP, LDK = L::LDK, LDW = L::LDW;
   extern __shared__ __attribute__((aligned(16))) char lc_sm[];
@@ -623,14 +632,23 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
   {
     constexpr int NK = (D2 * 64 + 255) / 256;                              // loads per thread: issued back to back, stored afterwards
     float kv[NK];
-#pragma unroll
-    for (int u = 0; u < NK; ++u) {
+    auto kidx = [&](int u) -> int64_t {
       int i = tid + u * 256;
       i = i < D2 * 64 ? i : D2 * 64 - 1;
       const int pxl = i / D2, t = i % D2;                                  // coalesced along the taps of one pixel
       int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
       y = y < H ? y : H - 1; x = x < W ? x : W - 1;
-      kv[u] = Kf[(((int64_t)b * H + y) * W + x) * ldk + t];
+      return (((int64_t)b * H + y) * W + x) * ldk + t;
+    };
+    if (kf_half) {                                                         // f16 rows out of the all-f16 fixup chain (one branch around the whole batch of loads)
+      uint16_t kh[NK];
+#pragma unroll
+      for (int u = 0; u < NK; ++u) kh[u] = reinterpret_cast<const uint16_t*>(Kf)[kidx(u)];
+#pragma unroll
+      for (int u = 0; u < NK; ++u) kv[u] = h2f(f16_t{kh[u]});
+    } else {
+#pragma unroll
+      for (int u = 0; u < NK; ++u) kv[u] = Kf[kidx(u)];
     }
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
@@ -830,6 +848,7 @@ struct JbuStage {
   float *range_temp, *sigma, *rp0_w, *rp0_b, *rp3_w, *rp3_b, *fx0_w, *fx0_b, *fx3_w, *fx3_b;
   // throughput mode: the two fixup linears on the bf16 MFMA GEMM, operands zero-padded to [NP, KP1] / [NP, NP] (NP, KP1 multiples of 64)
   void *fx0_w16, *fx3_w16; float *fx0_bp, *fx3_bp;
+  void *fx0_w16h, *fx3_w16h;                              // the same operands in f16: the all-2-byte fixup chain of the low-res path (round 3)
 };
 static inline int jbu_np(int r) { const int d = 2 * r + 1; return (int)align_up((size_t)d * d, 64); }
 static inline int jbu_kp1(int r) { const int d = 2 * r + 1; return (int)align_up((size_t)d * d + 3, 64); }
@@ -881,6 +900,7 @@ extern "C" int sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim) {
       for (int t = 0; t < 10; ++t) *slots[t] = (float*)take((size_t)stage_numel(t, r) * 4);
       S.fx0_w16 = take((size_t)jbu_np(r) * jbu_kp1(r) * 2); S.fx3_w16 = take((size_t)jbu_np(r) * jbu_np(r) * 2);
       S.fx0_bp = (float*)take((size_t)jbu_np(r) * 4); S.fx3_bp = (float*)take((size_t)jbu_np(r) * 4);
+      S.fx0_w16h = take((size_t)jbu_np(r) * jbu_kp1(r) * 2); S.fx3_w16h = take((size_t)jbu_np(r) * jbu_np(r) * 2);
     }
     j->fin_w = (float*)take((size_t)feat_dim * feat_dim * 4);
     j->fin_b = (float*)take((size_t)feat_dim * 4);
@@ -938,8 +958,8 @@ extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, 
           SG_LAUNCH_CHECK();
         }
         const int d2s = (2 * S.r + 1) * (2 * S.r + 1);
-        if (t == 6) SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16, jbu_kp1(S.r), 1, s));
-        if (t == 8) SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16, jbu_np(S.r), 1, s));
+        if (t == 6) { SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16, jbu_kp1(S.r), 1, s)); SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16h, jbu_kp1(S.r), HK_F16, s)); }
+        if (t == 8) { SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16, jbu_np(S.r), 1, s)); SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16h, jbu_np(S.r), HK_F16, s)); }
         if (t == 7) SG_HIP(hipMemcpyAsync(S.fx0_bp, slots[t], (size_t)d2s * 4, hipMemcpyDeviceToDevice, s));
         if (t == 9) SG_HIP(hipMemcpyAsync(S.fx3_bp, slots[t], (size_t)d2s * 4, hipMemcpyDeviceToDevice, s));
         j->have[set * 10 + t] = 1;
@@ -1013,6 +1033,9 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
     SG_LAUNCH_CHECK();
     const bool fast = precision == SG_PREC_BF16 && C % 8 == 0;       // throughput mode: bf16 MFMA for the fixup linears and the convolution
     const int NP = jbu_np(r), KP1 = jbu_kp1(r), ldk = fast ? NP : d2;
+    // the low-res path (below) runs its fixup chain in f16 end to end: operand rows, GELU output, residual and the kernel rows the convolution
+    // converts to f16 anyway -- 3040 -> 1792 bytes of HBM traffic per pixel and stage, and f16's 11 bits in place of bf16's 8 on the way
+    const bool h16 = fast && (r == 5 || r == 3) && lowres_ok;
     {
       const int WT = AC_T + 2 * r;
       const size_t lds = (size_t)WT * WT * JK_LD * sizeof(float);
@@ -1024,10 +1047,10 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
         const dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
         if (r == 5) {
           SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_mfma_kernel<5>), JkmCfg<5>::LDS));
-          hipLaunchKernelGGL(jbu_kernel_mfma_kernel<5>, grid, dim3(256), JkmCfg<5>::LDS, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1);
+          hipLaunchKernelGGL(jbu_kernel_mfma_kernel<5>, grid, dim3(256), JkmCfg<5>::LDS, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1, h16 ? 1 : 0);
         } else {
           SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_mfma_kernel<3>), JkmCfg<3>::LDS));
-          hipLaunchKernelGGL(jbu_kernel_mfma_kernel<3>, grid, dim3(256), JkmCfg<3>::LDS, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1);
+          hipLaunchKernelGGL(jbu_kernel_mfma_kernel<3>, grid, dim3(256), JkmCfg<3>::LDS, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1, h16 ? 1 : 0);
         }
       } else {
       SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jk), 64 * 1024));
@@ -1039,12 +1062,14 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
     SG_REQUIRE(pixels < (1ll << 31), "sg_jbu_upsample: too many pixels");
     if (fast) {  // H1 = GELU(X . W0^T + b0) (bf16);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3), columns >= d2 are padding
       GemmBf16Args g{};
-      g.A = p.X16; g.lda = KP1; g.W = (const bf16_t*)S.fx0_w16; g.ldw = KP1; g.bias = S.fx0_bp; g.C = p.H116; g.ldc = NP; g.c_is_bf16 = 1;
-      g.M = (int)pixels; g.N = NP; g.K = KP1; g.batch = 1; g.act = ACT_GELU; g.alpha = 1.f;
+      g.A = p.X16; g.lda = KP1; g.W = (const bf16_t*)(h16 ? S.fx0_w16h : S.fx0_w16); g.ldw = KP1; g.bias = S.fx0_bp; g.C = p.H116; g.ldc = NP; g.c_is_bf16 = 1;
+      g.M = (int)pixels; g.N = NP; g.K = KP1; g.batch = 1; g.act = ACT_GELU; g.alpha = 1.f; g.f16 = h16 ? 1 : 0;
       SG_TRY(gemm_bf16(g, s));
       GemmBf16Args q{};
-      q.A = p.H116; q.lda = NP; q.W = (const bf16_t*)S.fx3_w16; q.ldw = NP; q.bias = S.fx3_bp; q.residual = p.X; q.ldr = d2 + 3;
-      q.C = p.Kf; q.ldc = NP; q.c_is_bf16 = 0; q.M = (int)pixels; q.N = NP; q.K = NP; q.batch = 1; q.act = ACT_NONE; q.alpha = 0.1f;
+      q.A = p.H116; q.lda = NP; q.W = (const bf16_t*)(h16 ? S.fx3_w16h : S.fx3_w16); q.ldw = NP; q.bias = S.fx3_bp;
+      q.C = p.Kf; q.ldc = NP; q.M = (int)pixels; q.N = NP; q.K = NP; q.batch = 1; q.act = ACT_NONE; q.alpha = 0.1f;
+      if (h16) { q.residual = reinterpret_cast<const float*>(p.X16); q.ldr = KP1; q.res_half = 1; q.c_is_bf16 = 1; q.f16 = 1; }   // Kf rows in f16, residual = the operand rows
+      else { q.residual = p.X; q.ldr = d2 + 3; q.c_is_bf16 = 0; }
       SG_TRY(gemm_bf16(q, s));
     } else {  // fixup: H1 = GELU(X . W0^T + b0);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3)
       GemmF32Args g{};
@@ -1067,10 +1092,10 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
       dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
       if (r == 5) {
         SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_kernel<5>), LowCfg<5>::LDS));
-        hipLaunchKernelGGL(jbu_conv_lowres_kernel<5>, grid, dim3(256), LowCfg<5>::LDS, s, s16, p.Kf, ldk, h, w, C, d32, d16);
+        hipLaunchKernelGGL(jbu_conv_lowres_kernel<5>, grid, dim3(256), LowCfg<5>::LDS, s, s16, p.Kf, ldk, h, w, C, d32, d16, h16 ? 1 : 0);
       } else {
         SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_kernel<3>), LowCfg<3>::LDS));
-        hipLaunchKernelGGL(jbu_conv_lowres_kernel<3>, grid, dim3(256), LowCfg<3>::LDS, s, s16, p.Kf, ldk, h, w, C, d32, d16);
+        hipLaunchKernelGGL(jbu_conv_lowres_kernel<3>, grid, dim3(256), LowCfg<3>::LDS, s, s16, p.Kf, ldk, h, w, C, d32, d16, h16 ? 1 : 0);
       }
       SG_LAUNCH_CHECK();
       src = dst; h = oh; w = ow;
