@@ -849,6 +849,7 @@ struct JbuStage {
   // throughput mode: the two fixup linears on the bf16 MFMA GEMM, operands zero-padded to [NP, KP1] / [NP, NP] (NP, KP1 multiples of 64)
   void *fx0_w16, *fx3_w16; float *fx0_bp, *fx3_bp;
   void *fx0_w16h, *fx3_w16h;                              // the same operands in f16: the all-2-byte fixup chain of the low-res path (round 3)
+  void *fx0_wh2, *fx3_wh2;                                // ... and as two-plane f16 (SG_PREC_F16X2: f32-grade linears on the f16 matrix pipe)
 };
 static inline int jbu_np(int r) { const int d = 2 * r + 1; return (int)align_up((size_t)d * d, 64); }
 static inline int jbu_kp1(int r) { const int d = 2 * r + 1; return (int)align_up((size_t)d * d + 3, 64); }
@@ -863,6 +864,7 @@ struct sg_jbu {
   JbuStage st[4];
   float *fin_w, *fin_b;
   void* fin_w16;
+  void* fin_wh2;                                           // two-plane f16 copy of the final 1x1 weight (C % 32 == 0)
   std::vector<uint8_t> have;
 };
 
@@ -901,10 +903,12 @@ extern "C" int sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim) {
       S.fx0_w16 = take((size_t)jbu_np(r) * jbu_kp1(r) * 2); S.fx3_w16 = take((size_t)jbu_np(r) * jbu_np(r) * 2);
       S.fx0_bp = (float*)take((size_t)jbu_np(r) * 4); S.fx3_bp = (float*)take((size_t)jbu_np(r) * 4);
       S.fx0_w16h = take((size_t)jbu_np(r) * jbu_kp1(r) * 2); S.fx3_w16h = take((size_t)jbu_np(r) * jbu_np(r) * 2);
+      S.fx0_wh2 = take((size_t)jbu_np(r) * jbu_kp1(r) * 4); S.fx3_wh2 = take((size_t)jbu_np(r) * jbu_np(r) * 4);
     }
     j->fin_w = (float*)take((size_t)feat_dim * feat_dim * 4);
     j->fin_b = (float*)take((size_t)feat_dim * 4);
     j->fin_w16 = take((size_t)feat_dim * feat_dim * 2);
+    j->fin_wh2 = take((size_t)feat_dim * feat_dim * 4);
     bytes = align_up(off, 256);
   };
   lay(nullptr);
@@ -936,6 +940,7 @@ extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, 
   if (!strcmp(name, "fixup_proj.1.weight")) {
     SG_TRY(put(j->fin_w, (int64_t)j->C * j->C));
     if (j->C % 64 == 0) SG_TRY(pack_rows(src, j->C, j->C, j->C, j->fin_w16, j->C, 1, s));
+    if (j->C % 32 == 0) SG_TRY(pack_rows(src, j->C, j->C, j->C, j->fin_wh2, j->C, HK_F16X2, s));
     j->have[j->n_stage_sets * 10] = 1; return SG_OK;
   }
   if (!strcmp(name, "fixup_proj.1.bias")) {
@@ -958,8 +963,8 @@ extern "C" int sg_jbu_set_tensor(sg_jbu* j, const char* name, const float* src, 
           SG_LAUNCH_CHECK();
         }
         const int d2s = (2 * S.r + 1) * (2 * S.r + 1);
-        if (t == 6) { SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16, jbu_kp1(S.r), 1, s)); SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16h, jbu_kp1(S.r), HK_F16, s)); }
-        if (t == 8) { SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16, jbu_np(S.r), 1, s)); SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16h, jbu_np(S.r), HK_F16, s)); }
+        if (t == 6) { SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16, jbu_kp1(S.r), 1, s)); SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_w16h, jbu_kp1(S.r), HK_F16, s)); SG_TRY(pack_rows(src, d2s, d2s + 3, d2s + 3, S.fx0_wh2, jbu_kp1(S.r), HK_F16X2, s)); }
+        if (t == 8) { SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16, jbu_np(S.r), 1, s)); SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_w16h, jbu_np(S.r), HK_F16, s)); SG_TRY(pack_rows(src, d2s, d2s, d2s, S.fx3_wh2, jbu_np(S.r), HK_F16X2, s)); }
         if (t == 7) SG_HIP(hipMemcpyAsync(S.fx0_bp, slots[t], (size_t)d2s * 4, hipMemcpyDeviceToDevice, s));
         if (t == 9) SG_HIP(hipMemcpyAsync(S.fx3_bp, slots[t], (size_t)d2s * 4, hipMemcpyDeviceToDevice, s));
         j->have[set * 10 + t] = 1;
@@ -983,8 +988,8 @@ static size_t jbu_plan(const sg_jbu* j, int B, int gh, int gw, void* ws, bool dr
   p.X = (float*)take((size_t)pixels * (d2 + 3) * 4 + 1024);           // + slack: the padded fixup GEMM reads its residual NP columns wide
   p.H1 = (float*)take((size_t)pixels * d2 * 4);
   p.Kf = (float*)take((size_t)pixels * NP * 4);                       // row stride d2 (parity mode) or NP (throughput mode)
-  p.X16 = (bf16_t*)take((size_t)pixels * KP1 * 2);
-  p.H116 = (bf16_t*)take((size_t)pixels * NP * 2);
+  p.X16 = (bf16_t*)take((size_t)pixels * KP1 * 4);                      // 2-byte operand rows (throughput mode) or two-plane f16 ones (SG_PREC_F16X2: 4 bytes per element)
+  p.H116 = (bf16_t*)take((size_t)pixels * NP * 4);
   p.hr = (float*)take((size_t)pixels * j->C * 4);
   p.bufA = (float*)take((size_t)pixels / 4 * j->C * 4);                // stage-3 output (8x): ping
   p.bufB = (float*)take((size_t)pixels * j->C * 4);                    // stage-2 / stage-4 output: pong
@@ -1032,7 +1037,8 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
                        S.rp3_b, p.proj);
     SG_LAUNCH_CHECK();
     const bool fast = precision == SG_PREC_BF16 && C % 8 == 0;       // throughput mode: bf16 MFMA for the fixup linears and the convolution
-    const int NP = jbu_np(r), KP1 = jbu_kp1(r), ldk = fast ? NP : d2;
+    const bool x2 = precision == SG_PREC_F16X2;                       // exact tower mode: f32 kernels, the three linears as two-plane f16 GEMMs (f32-grade, 3 f16 MFMAs per product)
+    const int NP = jbu_np(r), KP1 = jbu_kp1(r), ldk = (fast || x2) ? NP : d2;
     // the low-res path (below) runs its fixup chain in f16 end to end: operand rows, GELU output, residual and the kernel rows the convolution
     // converts to f16 anyway -- 3040 -> 1792 bytes of HBM traffic per pixel and stage, and f16's 11 bits in place of bf16's 8 on the way
     const bool h16 = fast && (r == 5 || r == 3) && lowres_ok;
@@ -1070,6 +1076,16 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
       q.C = p.Kf; q.ldc = NP; q.M = (int)pixels; q.N = NP; q.K = NP; q.batch = 1; q.act = ACT_NONE; q.alpha = 0.1f;
       if (h16) { q.residual = reinterpret_cast<const float*>(p.X16); q.ldr = KP1; q.res_half = 1; q.c_is_bf16 = 1; q.f16 = 1; }   // Kf rows in f16, residual = the operand rows
       else { q.residual = p.X; q.ldr = d2 + 3; q.c_is_bf16 = 0; }
+      SG_TRY(gemm_bf16(q, s));
+    } else if (x2) {  // the same two linears on the two-plane GEMM: X rows packed to [KP1] two-plane, GELU output two-plane, Kf f32 rows of NP
+      SG_TRY(pack_rows(p.X, pixels, d2 + 3, d2 + 3, p.X16, KP1, HK_F16X2, s));
+      GemmBf16Args g{};
+      g.A = p.X16; g.lda = KP1; g.W = (const bf16_t*)S.fx0_wh2; g.ldw = KP1; g.bias = S.fx0_bp; g.C = p.H116; g.ldc = NP; g.c_is_bf16 = 1;
+      g.M = (int)pixels; g.N = NP; g.K = KP1; g.batch = 1; g.act = ACT_GELU; g.alpha = 1.f; g.h2 = 1;
+      SG_TRY(gemm_bf16(g, s));
+      GemmBf16Args q{};
+      q.A = p.H116; q.lda = NP; q.W = (const bf16_t*)S.fx3_wh2; q.ldw = NP; q.bias = S.fx3_bp; q.residual = p.X; q.ldr = d2 + 3;
+      q.C = p.Kf; q.ldc = NP; q.c_is_bf16 = 0; q.M = (int)pixels; q.N = NP; q.K = NP; q.batch = 1; q.act = ACT_NONE; q.alpha = 0.1f; q.h2 = 1;
       SG_TRY(gemm_bf16(q, s));
     } else {  // fixup: H1 = GELU(X . W0^T + b0);  Kf = X[:, :d2] + 0.1 * (H1 . W3^T + b3)
       GemmF32Args g{};
@@ -1147,6 +1163,13 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
     GemmBf16Args g{};
     g.A = (const bf16_t*)p.x16; g.lda = C; g.W = (const bf16_t*)j->fin_w16; g.ldw = C; g.bias = j->fin_b; g.residual = src; g.ldr = C;
     g.C = out; g.ldc = C; g.c_is_bf16 = 0; g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.act = 0; g.alpha = 0.1f;
+    return gemm_bf16(g, s);
+  }
+  if (precision == SG_PREC_F16X2 && C % 32 == 0 && pixels >= 1024) {   // exact tower mode: x packed to two-plane f16 (the hi-res scratch is free by now), f32-grade GEMM
+    SG_TRY(pack_rows(src, pixels, C, C, p.hr, C, HK_F16X2, s));
+    GemmBf16Args g{};
+    g.A = (const bf16_t*)p.hr; g.lda = C; g.W = (const bf16_t*)j->fin_wh2; g.ldw = C; g.bias = j->fin_b; g.residual = src; g.ldr = C;
+    g.C = out; g.ldc = C; g.c_is_bf16 = 0; g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.act = 0; g.alpha = 0.1f; g.h2 = 1;
     return gemm_bf16(g, s);
   }
   GemmF32Args g{};

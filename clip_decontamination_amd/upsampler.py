@@ -33,9 +33,10 @@ class HipJBU:
             raise RuntimeError("HipJBU needs a GPU: the hot path has no CPU implementation")
         self.model_name, self.feat_dim = model_name, feat_dim
         self.device = torch.device(device)
-        # the upsampler has a parity (f32) and a throughput (bf16) path: fp8 / f16 towers feed the bf16 one, the exact two-plane f16 tower the f32 one
+        # the upsampler has a parity (f32) and a throughput (bf16) path: fp8 / f16 towers feed the bf16 one; the exact two-plane f16 tower gets the
+        # f32 kernels with their three linears on the two-plane f16 GEMM (f32-grade results, SG_PREC_F16X2)
         pid = precision_id(precision)
-        self.precision = _lib.PREC_F32 if pid in (_lib.PREC_F32, _lib.PREC_F16X2) else _lib.PREC_BF16
+        self.precision = pid if pid in (_lib.PREC_F32, _lib.PREC_F16X2) else _lib.PREC_BF16
         self._ctx = C.c_void_p()
         self._ws = {}
         self.tiles_per_launch = 8            # tiles per JBU launch (workspace ~2.2 GB per 512-pixel tile)

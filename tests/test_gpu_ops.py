@@ -295,8 +295,9 @@ def test_adaptive_conv(ops, golden):
 
 
 # ---- SimFeatUp JBU ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
 @pytest.mark.parametrize("name", ["jbu_one", "jbu_stack"])
-def test_jbu_matches_reference_fixture(golden, name):
+def test_jbu_matches_reference_fixture(golden, name, prec):
     """End-to-end upsampler against the fixture minted from the reference modules (adaptive conv = the reference's
     in-tree torch form of FeatUp's CUDA op; third party, unpinned -- see oracle/jbu.py)."""
     from clip_decontamination_amd import weights as Wt
@@ -304,7 +305,7 @@ def test_jbu_matches_reference_fixture(golden, name):
     g = golden("jbu")
     src, guid = torch.from_numpy(g[f"{name}.src"]), torch.from_numpy(g[f"{name}.guidance"])
     C = src.shape[1]
-    up = get_upsampler(name, C, DEV, "f32")
+    up = get_upsampler(name, C, DEV, prec)                 # f16x2: the f32 kernels with the three linears on the two-plane f16 GEMM -- same bound
     up.load_state_dict(Wt.make_jbu_weights(name, C, seed=3))
     out = up(src.to(DEV), guid.to(DEV))
     ref = torch.from_numpy(g[f"{name}.out"])
@@ -350,7 +351,7 @@ def test_jbu_throughput_mode_lowres_conv_vs_oracle(name, C, gh, gw):
     assert rel < 1.5e-2, rel
 
 
-@pytest.mark.parametrize("name,prec,tol", [("jbu_one", "f32", 2e-4), ("jbu_one", "bf16", 1.5e-2), ("jbu_stack", "bf16", 1.5e-2)])
+@pytest.mark.parametrize("name,prec,tol", [("jbu_one", "f32", 2e-4), ("jbu_one", "f16x2", 2e-4), ("jbu_stack", "f16x2", 2e-4), ("jbu_one", "bf16", 1.5e-2), ("jbu_stack", "bf16", 1.5e-2)])
 def test_jbu_512_launch_shape_vs_oracle(name, prec, tol):
     """The launch shape of `bench.py --upsampler` / BASELINE configs[3]: a 32 x 32 token grid taken 16x to 512 x 512 pixels (stages 64, 128, 256, 512),
     on a 64-channel slice so that the oracle (tap loop, no unfold) finishes in seconds.  Every stage's grid, the reflect borders of the 512 stage and the
