@@ -800,6 +800,223 @@ __global__ __launch_bounds__(256, 2) void jbu_conv_lowres_kernel(const bf16_t* _
   }
 }
 
+// ---- the same low-res adaptive convolution for the EXACT tower mode (SG_PREC_F16X2, round 3) ------------------------------------------------
+// f32-grade results on the f16 matrix pipe, as the tower's linears have them: Keff is built in f32 (the scalar arithmetic the kernel above
+// started from) and split into two f16 planes F_hi + F_lo, the source rows are two-plane f16 (h2_t: [8 hi | 8 lo] per 8 channels, staged as they
+// lie in HBM: 512 bytes per window position and 128-channel chunk), and every product is Win_hi.F_hi + Win_lo.F_hi + Win_hi.F_lo into one f32
+// accumulator.  Stage outputs stay two-plane (the next stage's source), the last stage writes f32.  130 KB of LDS at r = 5: one workgroup per CU.
+template <int R> struct LowX2Cfg {
+  using L = LowCfg<R>;
+  static constexpr int LDWB = ACM_CC * 4 + 32;                          // window row stride in BYTES: 128 two-plane channels + 32 (rows 8 banks apart)
+  static constexpr size_t F_BYTES = (size_t)2 * 64 * L::LDK * 2;        // F_hi, F_lo
+  static constexpr size_t W_BYTES = (size_t)L::KP * LDWB;
+  static constexpr size_t K_BYTES = (size_t)64 * L::D2 * 4 + (size_t)2 * 8 * L::D * L::LWP * 4;
+  static constexpr size_t LDS = F_BYTES + (W_BYTES > K_BYTES ? W_BYTES : K_BYTES);
+};
+template <int R>
+__global__ __launch_bounds__(256) void jbu_conv_lowres_x2_kernel(const h2_t* __restrict__ src, const float* __restrict__ Kf, int ldk, int h, int w,
+                                                                 int C, float* __restrict__ out, h2_t* __restrict__ out2) {
+  using L = LowCfg<R>;
+  using X = LowX2Cfg<R>;
+  constexpr int D = L::D, D2 = L::D2, LW = L::LW, LWP = L::LWP, KP = L::KP, LDK = L::LDK, LDWB = X::LDWB;
+  extern __shared__ __attribute__((aligned(16))) char lx_sm[];
+  uint16_t* sFh = reinterpret_cast<uint16_t*>(lx_sm);                     // [64][LDK] f16
+  uint16_t* sFl = sFh + 64 * LDK;
+  char* sW = lx_sm + X::F_BYTES;                                          // [KP][LDWB]           (chunk loop)
+  float* sK = reinterpret_cast<float*>(lx_sm + X::F_BYTES);              // [64][D2]             (Keff build; aliases sW)
+  float* sWx = sK + 64 * D2;                                              // [8][D][LWP]
+  float* sWy = sWx + 8 * D * LWP;
+  const int H = 2 * h, W = 2 * w;
+  const int tiles_x = (W + AC_T - 1) / AC_T;
+  const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+  const int ty0 = (blk / tiles_x) * AC_T, tx0 = (blk % tiles_x) * AC_T;
+  const int ly0 = ty0 / 2 - L::OFF, lx0 = tx0 / 2 - L::OFF;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- 1. tables + the block's kernel rows (f32) ----
+  if (tid < 2 * 8 * D) {
+    const bool isy = tid >= 8 * D;
+    const int e = isy ? tid - 8 * D : tid, pl = e / D, t = e % D;
+    const int size = isy ? H : W, lo_size = isy ? h : w, org = isy ? ty0 : tx0, lorg = isy ? ly0 : lx0;
+    int u = org + pl + t - R;
+    u = u > size - 1 + R ? size - 1 + R : u;
+    u = reflect_idx(u, size);
+    int idx[4]; float wt[4];
+    cubic_taps(u, lo_size, size, idx, wt);
+    float* row = (isy ? sWy : sWx) + (pl * D + t) * LWP;
+#pragma unroll
+    for (int c = 0; c < LWP; ++c) row[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int c = idx[k] - lorg;
+      c = c < 0 ? 0 : (c > LW - 1 ? LW - 1 : c);
+      row[isy ? c : c + c / 3] += wt[k];                                   // x rows: column 3q + j at slot 4q + j
+    }
+  }
+  {
+    constexpr int NK = (D2 * 64 + 255) / 256;
+    float kv[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      int i = tid + u * 256;
+      i = i < D2 * 64 ? i : D2 * 64 - 1;
+      const int pxl = i / D2, t = i % D2;
+      int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+      y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+      kv[u] = Kf[(((int64_t)b * H + y) * W + x) * ldk + t];
+    }
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      const int i = tid + u * 256;
+      if (i < D2 * 64) sK[i] = kv[u];
+    }
+  }
+  __syncthreads();
+  // ---- 2. Keff = Wy^T . K . Wx in f32, split into two f16 planes ----
+  {
+    const int p = tid >> 2, q = tid & 3, py = p >> 3, px = p & 7;
+    const float* kp = sK + p * D2;
+    const float* wx = sWx + px * D * LWP + 4 * q;
+    const float* wy = sWy + py * D * LWP;
+    float T[D][3];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float kv = kp[i * D + j];
+        t0 += kv * wx[j * LWP]; t1 += kv * wx[j * LWP + 1]; t2 += kv * wx[j * LWP + 2];
+      }
+      T[i][0] = t0; T[i][1] = t1; T[i][2] = t2;
+    }
+    float e[LW][3];
+#pragma unroll
+    for (int ly = 0; ly < LW; ++ly) { e[ly][0] = 0.f; e[ly][1] = 0.f; e[ly][2] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int ly = 0; ly < LW; ++ly) {
+        const float wv = wy[i * LWP + ly];
+        e[ly][0] += wv * T[i][0]; e[ly][1] += wv * T[i][1]; e[ly][2] += wv * T[i][2];
+      }
+    constexpr int QW = L::QW;
+    uint32_t ph[QW / 2], pl[QW / 2];
+#pragma unroll
+    for (int j = 0; j < QW / 2; ++j) {
+      const int i0 = 2 * j, i1 = 2 * j + 1;
+      const float v0 = i0 < 3 * LW ? e[i0 / 3 < LW ? i0 / 3 : 0][i0 % 3] : 0.f;
+      const float v1 = i1 < 3 * LW ? e[i1 / 3 < LW ? i1 / 3 : 0][i1 % 3] : 0.f;
+      split_h2(v0, v1, ph[j], pl[j]);
+    }
+    uint16_t* fh = sFh + p * LDK + q * QW;
+    uint16_t* fl = sFl + p * LDK + q * QW;
+#pragma unroll
+    for (int j = 0; j < QW / 4; ++j) {
+      *reinterpret_cast<uint2*>(fh + 4 * j) = make_uint2(ph[2 * j], ph[2 * j + 1]);
+      *reinterpret_cast<uint2*>(fl + 4 * j) = make_uint2(pl[2 * j], pl[2 * j + 1]);
+    }
+    if constexpr (KP > L::NPOS) {
+      static_assert((KP - L::NPOS) == 16, "padding is written as one 8-byte piece per thread");
+      *reinterpret_cast<uint2*>(sFh + p * LDK + L::NPOS + 4 * q) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(sFl + p * LDK + L::NPOS + 4 * q) = make_uint2(0u, 0u);
+    }
+  }
+  const h2_t* sb = src + (int64_t)b * h * w * C;
+  for (int c0 = 0; c0 < C; c0 += ACM_CC) {
+    __syncthreads();                                                       // F complete / Keff build done with sK / previous chunk's MFMAs done with sW
+    // ---- 3a. window [K slot][128 two-plane channels] as it lies in HBM: 32 x 16-byte pieces per position, two rounds of loads ----
+    {
+      constexpr int NPC = ACM_CC * 4 / 16;                                 // 16-byte pieces per position and chunk
+      constexpr int NS = KP * NPC / 256 / 2;
+      static_assert(KP * NPC % 512 == 0, "window pieces must divide over the threads and the two rounds");
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        uint4 wv[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          const int i = tid + (half * NS + u) * 256, pos = i / NPC, pc16 = i % NPC;
+          const int pc = pos < L::NPOS ? pos : L::NPOS - 1;
+          const int qd = pc / L::QW, rem = pc % L::QW;
+          const int wy_ = rem / 3 < LW ? rem / 3 : LW - 1, wx_ = 3 * qd + rem % 3 < LW ? 3 * qd + rem % 3 : LW - 1;
+          int sy = ly0 + wy_, sx = lx0 + wx_;
+          sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy); sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);
+          int cc = c0 + 4 * pc16; cc = cc + 4 <= C ? cc : C - 4;           // piece = 4 h2 elements' worth of bytes: element index c0 + 4 * piece (ragged last chunk: a valid duplicate)
+          wv[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sb + ((int64_t)sy * w + sx) * C) + (int64_t)cc * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          const int i = tid + (half * NS + u) * 256, pos = i / NPC, pc16 = i % NPC;
+          *reinterpret_cast<uint4*>(sW + pos * LDWB + 16 * pc16) = wv[u];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3b. wave: channels [32 wave, +32) x 64 pixels, three f16 MFMAs per product ----
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((ext_vector_type(4))) short s4_t;
+    typedef __attribute__((address_space(3))) s4_t* lds_s4_t;
+    typedef __attribute__((ext_vector_type(8))) short s8_t;
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll 1
+    for (int k0 = 0; k0 < KP; k0 += 32) {
+      bf16x8 fah[4], fal[4], fwh[2], fwl[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        fah[mi] = *reinterpret_cast<const bf16x8*>(sFh + (mi * 16 + (lane & 15)) * LDK + k0 + g * 8);
+        fal[mi] = *reinterpret_cast<const bf16x8*>(sFl + (mi * 16 + (lane & 15)) * LDK + k0 + g * 8);
+      }
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        // channels 32 wave + 16 nj + 4 pp .. + 3 of rows k0 + 8 g + qq (and + 4): storage group (8 channels) gi, first / second half of its plane
+        const int gi = wave * 4 + nj * 2 + (pp >> 1);
+        const char* p0 = sW + (k0 + 8 * g + qq) * LDWB + gi * 32 + (pp & 1) * 8;
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane) {
+          const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(p0 + plane * 16));
+          const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(p0 + plane * 16 + 4 * LDWB));
+          const s8_t both = (s8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (plane == 0) fwh[nj] = __builtin_bit_cast(bf16x8, both); else fwl[nj] = __builtin_bit_cast(bf16x8, both);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          acc[mi][nj] = mfma_16x16x32<true>(fwh[nj], fah[mi], acc[mi][nj]);
+          acc[mi][nj] = mfma_16x16x32<true>(fwl[nj], fah[mi], acc[mi][nj]);
+          acc[mi][nj] = mfma_16x16x32<true>(fwh[nj], fal[mi], acc[mi][nj]);
+        }
+    }
+    // lane: pixel mi*16 + (lane & 15), channels c0 + 32 wave + 16 nj + 4 (lane >> 4) .. +4
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int pxl = mi * 16 + (lane & 15);
+      const int y = ty0 + (pxl >> 3), x = tx0 + (pxl & 7);
+      if (y < H && x < W) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          const int c = c0 + wave * 32 + nj * 16 + (lane >> 4) * 4;
+          if (c < C) {
+            const int64_t o = (((int64_t)b * H + y) * W + x) * C + c;
+            if (out) *reinterpret_cast<float4*>(out + o) = make_float4(acc[mi][nj][0], acc[mi][nj][1], acc[mi][nj][2], acc[mi][nj][3]);
+            if (out2) {                                                    // two-plane row: element c sits in group c >> 3, half (c >> 2) & 1
+              uint2 hv, lv;
+              split_h2(acc[mi][nj][0], acc[mi][nj][1], hv.x, lv.x); split_h2(acc[mi][nj][2], acc[mi][nj][3], hv.y, lv.y);
+              char* g8 = reinterpret_cast<char*>(out2 + (o & ~(int64_t)7)) + ((c >> 2) & 1) * 8;
+              *reinterpret_cast<uint2*>(g8) = hv; *reinterpret_cast<uint2*>(g8 + 16) = lv;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // Stand-alone adaptive convolution in FeatUp's NCHW calling convention
 // (featup.adaptive_conv_cuda.AdaptiveConv.apply as used at upsamplers.py:274; semantics restated from
 // adaptive_conv_py_simple, upsamplers.py:14-25):  out[b,c,y,x] = sum_{i,j<d} in[b,c,y+i,x+j] * filt[b,y,x,i,j]
@@ -1023,6 +1240,15 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
     size_t off = align_up((size_t)B * gh * gw * C * 2, 256);
     for (int t = 0; t < 3; ++t) { o16[t] = (bf16_t*)((char*)p.hr + off); off += align_up((size_t)B * (gh << (t + 1)) * (gw << (t + 1)) * C * 2, 256); }
   }
+  // exact tower mode: the same low-res formulation on two-plane f16 operands (jbu_conv_lowres_x2_kernel); its stage outputs (4 bytes per element)
+  // live where the hi-res tensor would have
+  const bool x2low_ok = precision == SG_PREC_F16X2 && C % 64 == 0 && gh >= 2 && gw >= 2;
+  h2_t* tok2 = (h2_t*)p.hr;
+  h2_t* o2[3];
+  {
+    size_t off = align_up((size_t)B * gh * gw * C * 4, 256);
+    for (int t = 0; t < 3; ++t) { o2[t] = (h2_t*)((char*)p.hr + off); off += align_up((size_t)B * (gh << (t + 1)) * (gw << (t + 1)) * C * 4, 256); }
+  }
   for (int stg = 0; stg < 4; ++stg) {
     const JbuStage& S = j->st[j->kind == 0 ? 0 : stg];
     const int r = S.r, d = 2 * r + 1, d2 = d * d, oh = 2 * h, ow = 2 * w;
@@ -1096,6 +1322,23 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
       q.A = p.H1; q.lda = d2; q.B = S.fx3_w; q.sbk = 1; q.sbn = d2; q.bias = S.fx3_b; q.residual = p.X; q.ldr = d2 + 3; q.C = p.Kf; q.ldc = d2;
       q.M = (int)pixels; q.N = d2; q.K = d2; q.batch = 1; q.inner = 1; q.act = ACT_NONE; q.alpha = 0.1f;
       SG_TRY(gemm_f32(q, s));
+    }
+    if (x2 && x2low_ok && (r == 5 || r == 3)) {
+      const h2_t* s2 = stg == 0 ? tok2 : o2[stg - 1];
+      if (stg == 0) SG_TRY(pack_rows(source, (int64_t)B * gh * gw, C, C, tok2, C, HK_F16X2, s));
+      h2_t* d2 = stg == 3 ? nullptr : o2[stg];
+      float* d32 = stg == 3 ? dst : nullptr;
+      dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
+      if (r == 5) {
+        SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_x2_kernel<5>), LowX2Cfg<5>::LDS));
+        hipLaunchKernelGGL(jbu_conv_lowres_x2_kernel<5>, grid, dim3(256), LowX2Cfg<5>::LDS, s, s2, p.Kf, ldk, h, w, C, d32, d2);
+      } else {
+        SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_x2_kernel<3>), LowX2Cfg<3>::LDS));
+        hipLaunchKernelGGL(jbu_conv_lowres_x2_kernel<3>, grid, dim3(256), LowX2Cfg<3>::LDS, s, s2, p.Kf, ldk, h, w, C, d32, d2);
+      }
+      SG_LAUNCH_CHECK();
+      src = dst; h = oh; w = ow;
+      continue;
     }
     const bool mfma_conv = fast;
     const bool lowres = fast && (r == 5 || r == 3) && lowres_ok;   // bicubic folded into the per-pixel kernel: no hi-res tensor at all

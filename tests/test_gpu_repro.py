@@ -27,7 +27,7 @@ def _same(outs, what):
 
 
 @pytest.mark.parametrize("name", ["jbu_one", "jbu_stack"])
-@pytest.mark.parametrize("prec", ["bf16", "f32"])
+@pytest.mark.parametrize("prec", ["bf16", "f16x2", "f32"])
 def test_jbu_is_reproducible(name, prec):
     """32 x 32 tokens -> 512 x 512 (4096 workgroups in the last stage: eight rounds on 256 CUs x 2 slots)."""
     from clip_decontamination_amd.upsampler import get_upsampler
