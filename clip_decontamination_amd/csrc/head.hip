@@ -296,11 +296,129 @@ extern "C" int sg_render_maps(const int64_t* labels, const float* probs, const u
   return SG_OK;
 }
 
+namespace sg {
+// Large-n form without the global debias (per-pixel logits behind the upsampler): logits = (x / |x|) . T^T is a [n, E] x [E, 16] GEMM.
+// f32-grade on the f16 matrix pipe: T as two f16 planes in LDS, the f32 rows split into hi + lo on the fly, three v_mfma_f32_16x16x32_f16
+// per product into one f32 accumulator (the same scheme as SG_PREC_F16X2's GEMMs), |x|^2 in f32 from the loaded values.  A wave owns 64
+// consecutive pixels per round; a lane ends with 4 consecutive pixels of one query.  Bound by the read of x (the lane-per-token kernel
+// above runs this shape at 1.5 TB/s on the vector pipe: 5.9 ms per 8 tiles of 592 x 592 at E = 768).
+constexpr int CLM_ROUNDS = 4;
+__global__ __launch_bounds__(256, 2) void cosine_logits_mfma_kernel(const float* __restrict__ tokens, const float* __restrict__ cls,
+                                                                    const float* __restrict__ text, int n, int E, int Q, float lambda,
+                                                                    float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) char clm_sm[];
+  const int ldt = E + 8;
+  uint16_t* sTh = reinterpret_cast<uint16_t*>(clm_sm);                   // [16][E + 8] f16
+  uint16_t* sTl = sTh + 16 * ldt;
+  float* sN = reinterpret_cast<float*>(sTl + 16 * ldt);                   // [4 waves][64]
+  float* sCL = sN + 4 * 64;                                               // [16] lambda * cls logits of this image
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 16 * E; i += 256) {
+    const int q = i / E, c = i % E;
+    const float v = q < Q ? text[(int64_t)q * E + c] : 0.f;
+    const f16_t hi = f2h(v);
+    sTh[q * ldt + c] = hi.bits;
+    sTl[q * ldt + c] = f2h(v - h2f(hi)).bits;
+  }
+  if (tid < 16) sCL[tid] = 0.f;
+  __syncthreads();
+  if (cls != nullptr && lambda != 0.f) {                                   // lambda * (cls / |cls|) . T[q]   (segmentor.py:310-311, 379), f32
+    const float* cr = cls + (int64_t)b * E;
+    float ss = 0.f;
+    for (int i = lane; i < E; i += 64) ss += cr[i] * cr[i];
+    const float inv = 1.0f / sqrtf(wave_sum(ss));
+    for (int q = wave; q < Q; q += 4) {
+      float d = 0.f;
+      for (int i = lane; i < E; i += 64) d += cr[i] * text[(int64_t)q * E + i];
+      d = wave_sum(d);
+      if (lane == 0) sCL[q] = lambda * d * inv;
+    }
+    __syncthreads();
+  }
+  const int r = lane & 15, g = lane >> 4;
+  float* myN = sN + wave * 64;
+  const float* xb = tokens + (int64_t)b * n * E;
+  float* lb = logits + (int64_t)b * Q * n;
+  for (int round = 0; round < CLM_ROUNDS; ++round) {
+    const int pix0 = ((blockIdx.x * CLM_ROUNDS + round) * 4 + wave) * 64;
+    if (pix0 >= n) return;                                                // wave-uniform; no workgroup barrier below
+    const float* xr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int pr = pix0 + t * 16 + r;
+      pr = pr < n ? pr : n - 1;
+      xr[t] = xb + (int64_t)pr * E + 8 * g;
+    }
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float nx[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 cur[4][2], nxt[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { cur[t][0] = *reinterpret_cast<const float4*>(xr[t]); cur[t][1] = *reinterpret_cast<const float4*>(xr[t] + 4); }
+    const int nk = E / 32;
+    for (int ks = 0; ks < nk; ++ks) {
+      const int kn = ks + 1 < nk ? ks + 1 : ks;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { nxt[t][0] = *reinterpret_cast<const float4*>(xr[t] + 32 * kn); nxt[t][1] = *reinterpret_cast<const float4*>(xr[t] + 32 * kn + 4); }
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sTh + r * ldt + 32 * ks + 8 * g);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sTl + r * ldt + 32 * ks + 8 * g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v[8] = {cur[t][0].x, cur[t][0].y, cur[t][0].z, cur[t][0].w, cur[t][1].x, cur[t][1].y, cur[t][1].z, cur[t][1].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) nx[t] = __builtin_fmaf(v[e], v[e], nx[t]);
+        uint4 hi, lo;
+        split_h2x8(v, hi, lo);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
+        acc[t] = mfma_16x16x32<true>(ah, bh, acc[t]);                      // D[pixel i][query j]: lane = j + 16 (i / 4), 4 consecutive pixels
+        acc[t] = mfma_16x16x32<true>(al, bh, acc[t]);
+        acc[t] = mfma_16x16x32<true>(ah, bl, acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { cur[t][0] = nxt[t][0]; cur[t][1] = nxt[t][1]; }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { nx[t] += __shfl_xor(nx[t], 16, 64); nx[t] += __shfl_xor(nx[t], 32, 64); }
+    if (g == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) myN[t * 16 + r] = 1.0f / fmaxf(sqrtf(nx[t]), 1e-12f);   // F.normalize's eps
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (r < Q) {
+      const float cl = sCL[r];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pix = pix0 + t * 16 + 4 * g;
+        if (pix >= n) continue;
+        const float4 inv = *reinterpret_cast<const float4*>(myN + t * 16 + 4 * g);
+        const float o[4] = {acc[t][0] * inv.x + cl, acc[t][1] * inv.y + cl, acc[t][2] * inv.z + cl, acc[t][3] * inv.w + cl};
+        float* dst = lb + (int64_t)r * n + pix;
+        if (pix + 3 < n && (n & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
+          for (int e = 0; e < 4; ++e) if (pix + e < n) dst[e] = o[e];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace sg
+
 extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const float* text, int B, int n, int E, int Q,
                                 float global_debias_factor, float cls_token_lambda, float* logits, sg_stream s) {
   SG_REQUIRE(tokens && text && logits, "sg_cosine_logits: null pointer");
   SG_REQUIRE(B > 0 && n > 0 && E > 0 && Q > 0 && B < 65536, "sg_cosine_logits: bad shape B=%d n=%d E=%d Q=%d", B, n, E, Q);
   SG_REQUIRE(cls || (global_debias_factor == 0.f && cls_token_lambda == 0.f), "sg_cosine_logits: cls required for debias / lambda");
+  if (global_debias_factor == 0.f && Q <= 16 && E % 32 == 0 && n >= 16384 && (((uintptr_t)logits) & 15) == 0) {   // per-pixel logits: the matrix-pipe form
+    const size_t ldsm = (size_t)2 * 16 * (E + 8) * 2 + (4 * 64 + 16) * sizeof(float);
+    if (ldsm <= 160 * 1024) {
+      if (ldsm > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sg::cosine_logits_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+      hipLaunchKernelGGL(sg::cosine_logits_mfma_kernel, dim3((unsigned)cdiv(n, 4 * 64 * sg::CLM_ROUNDS), (unsigned)B), dim3(256), ldsm, as_stream(s), tokens, cls, text,
+                         n, E, Q, cls_token_lambda, logits);
+      SG_LAUNCH_CHECK();
+      return SG_OK;
+    }
+  }
   const size_t lds = ((size_t)Q * E + E + Q) * sizeof(float);
   SG_REQUIRE(lds <= 160 * 1024, "sg_cosine_logits: Q*E=%d exceeds LDS", Q * E);
   SG_REQUIRE(E <= 64 * CL_MAXV && E % 4 == 0, "sg_cosine_logits: E=%d must be a multiple of 4 and <= %d", E, 64 * CL_MAXV);
