@@ -1228,7 +1228,7 @@ extern "C" size_t sg_jbu_workspace_bytes(const sg_jbu* j, int B, int gh, int gw)
 // The four 2x stages (JBULearnedRange.forward x 4): source [B, gh*gw, C] -> *x_out [B, 16gh*16gw, C] f32 inside the workspace
 // (and its bf16 copy in p.x16 in throughput mode when C % 64 == 0)
 static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int B, int gh, int gw, int GH, int GW, int precision,
-                      const JbuPlan& p, const float** x_out, hipStream_t s, bool want_f32_x = true) {
+                      const JbuPlan& p, const float** x_out, hipStream_t s, bool want_f32_x = true, bool* x2_in_hr = nullptr) {
   const int C = j->C;
   const float* src = source;
   int h = gh, w = gw;
@@ -1248,7 +1248,11 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
   {
     size_t off = align_up((size_t)B * gh * gw * C * 4, 256);
     for (int t = 0; t < 3; ++t) { o2[t] = (h2_t*)((char*)p.hr + off); off += align_up((size_t)B * (gh << (t + 1)) * (gw << (t + 1)) * C * 4, 256); }
+    // the 8x stage's output goes to the f32 path's 8x buffer (bufA: exactly pixels / 4 x C x 4 bytes, unused by this chain) instead: the hi-res
+    // region is then dead while the LAST stage runs, which writes the two-plane copy of x there for the final 1x1 GEMM -- no pack pass
+    o2[2] = (h2_t*)p.bufA;
   }
+  if (x2_in_hr) *x2_in_hr = false;
   for (int stg = 0; stg < 4; ++stg) {
     const JbuStage& S = j->st[j->kind == 0 ? 0 : stg];
     const int r = S.r, d = 2 * r + 1, d2 = d * d, oh = 2 * h, ow = 2 * w;
@@ -1326,8 +1330,9 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
     if (x2 && x2low_ok && (r == 5 || r == 3)) {
       const h2_t* s2 = stg == 0 ? tok2 : o2[stg - 1];
       if (stg == 0) SG_TRY(pack_rows(source, (int64_t)B * gh * gw, C, C, tok2, C, HK_F16X2, s));
-      h2_t* d2 = stg == 3 ? nullptr : o2[stg];
+      h2_t* d2 = stg == 3 ? (x2_in_hr ? (h2_t*)p.hr : nullptr) : o2[stg];
       float* d32 = stg == 3 ? dst : nullptr;
+      if (stg == 3 && x2_in_hr) *x2_in_hr = true;
       dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
       if (r == 5) {
         SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_conv_lowres_x2_kernel<5>), LowX2Cfg<5>::LDS));
@@ -1398,7 +1403,8 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
   if (need > ws_bytes) return fail(SG_ERR_STATE, "sg_jbu_upsample: workspace %zu < required %zu", ws_bytes, need);
   const int C = j->C;
   const float* src = nullptr;
-  SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &src, s));
+  bool x2_ready = false;
+  SG_TRY(jbu_stages(j, source, guidance, B, gh, gw, GH, GW, precision, p, &src, s, true, &x2_ready));
   // out = x + 0.1 * (x . Wf^T + bf)     (bias pre-scaled by 0.1 at load)
   const int64_t pixels = (int64_t)B * 16 * gh * 16 * gw;
   if (precision == SG_PREC_BF16 && C % 64 == 0) {
@@ -1409,7 +1415,7 @@ extern "C" int sg_jbu_upsample(sg_jbu* j, const float* source, const float* guid
     return gemm_bf16(g, s);
   }
   if (precision == SG_PREC_F16X2 && C % 32 == 0 && pixels >= 1024) {   // exact tower mode: x packed to two-plane f16 (the hi-res scratch is free by now), f32-grade GEMM
-    SG_TRY(pack_rows(src, pixels, C, C, p.hr, C, HK_F16X2, s));
+    if (!x2_ready) SG_TRY(pack_rows(src, pixels, C, C, p.hr, C, HK_F16X2, s));   // (the two-plane low-res convolution wrote this copy itself)
     GemmBf16Args g{};
     g.A = (const bf16_t*)p.hr; g.lda = C; g.W = (const bf16_t*)j->fin_wh2; g.ldw = C; g.bias = j->fin_b; g.residual = src; g.ldr = C;
     g.C = out; g.ldc = C; g.c_is_bf16 = 0; g.M = (int)pixels; g.N = C; g.K = C; g.batch = 1; g.act = 0; g.alpha = 0.1f; g.h2 = 1;
