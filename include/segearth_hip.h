@@ -226,7 +226,7 @@ int sg_op_linear(const float* A, const float* W, const float* bias, const float*
  * fold = 0 runs the LayerNorm as its own pass; fold = 1 is what the towers do in the 2-byte modes: the first GEMM's epilogue also writes the
  * 2-byte copy of x and per-64-column (sum, centred sum of squares), the second GEMM runs on that copy with W' = gamma o W2 and applies
  * rstd (acc - mean c) + b' in its epilogue (c = row sums of W', b' = b2 + W2.beta) -- no pass over x in between.
- * precision: SG_PREC_BF16 / SG_PREC_F16; fold needs M >= 1024, D >= 512, D % 64 == 0, N2 >= 512.  All pointers are f32 device memory. */
+ * precision: SG_PREC_BF16 / SG_PREC_F16 / SG_PREC_F16X2; fold needs M >= 1024, D >= 512, D % 64 == 0, N2 >= 512.  All pointers are f32 device memory. */
 size_t sg_op_ln_chain_scratch_bytes(int M, int K1, int D, int N2);
 int sg_op_ln_chain(const float* A, const float* W1, const float* b1, float* x, const float* gamma, const float* beta, const float* W2,
                    const float* b2, float* y, int M, int K1, int D, int N2, int act, int precision, int fold, void* scratch,
@@ -291,7 +291,9 @@ int  sg_text_encode(sg_text* t, const int32_t* tokens, int n_seq, float* out, vo
  * sg_jbu_set_tensor takes the tensors by their state-dict names ("up.range_temp", "up2.fixup_proj.0.weight",
  * "fixup_proj.1.weight" ...), i.e. load_state_dict (segmentor.py:281-283);
  * sg_jbu_upsample replaces self.upsampler(image_features, img) (segmentor.py:371 -> upsamplers.py:278-325):
- *   source [B, gh*gw, C] patch tokens (pixel-major), guidance [B,3,GH,GW] normalised tile -> out [B, 16gh*16gw, C]. */
+ *   source [B, gh*gw, C] patch tokens (pixel-major), guidance [B,3,GH,GW] normalised tile -> out [B, 16gh*16gw, C].
+ *   precision: SG_PREC_F32 (parity kernels), SG_PREC_F16X2 (f32-grade: the linears and the low-res adaptive convolution on three f16 MFMAs per
+ *   product -- what an exact tower mode is paired with), SG_PREC_BF16 (throughput: low-res convolution on bf16 operands, f16 fixup chain). */
 typedef struct sg_jbu sg_jbu;
 int  sg_jbu_create(sg_jbu** out, int device, int kind, int feat_dim);
 void sg_jbu_destroy(sg_jbu* j);
