@@ -443,9 +443,48 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const InT* __restrict_
   const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
   for (int i = lane; i < D; i += 64) st_elem<OutT>(yr, i, ld_elem<InT>(xr, i) * inv);
 }
+// Short rows (head vectors: D <= 128, D % 8 == 0): LPR = 8 or 16 lanes per row, 8 elements per lane, the sum of squares over the row's lanes on
+// DPP adds -- 8 / 4 rows per wave instead of one row per wave with a single element per lane and six ds_bpermute round trips (GEM's q / k / v
+// normalisations: 665 us per call at 119 tiles of ViT-L/14, 10.6 % of the BASELINE config-3 step).
+template <typename InT, typename OutT, int LPR>
+__global__ __launch_bounds__(256) void l2norm_rows_short_kernel(const InT* __restrict__ x, int64_t so, int64_t si, int inner,
+                                                                OutT* __restrict__ y, int64_t yo, int64_t yi, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63, sub = lane / LPR, l = lane % LPR;
+  constexpr int RPW = 64 / LPR;
+  int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+  const bool live = row < rows;
+  row = live ? row : rows - 1;
+  const InT* xr = x + (row / inner) * so + (row % inner) * si;
+  OutT* yr = y + (row / inner) * yo + (row % inner) * yi;
+  const bool mine = 8 * l < D;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = mine ? ld_elem<InT>(xr, 8 * l + e) : 0.f;
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+  ss = LPR == 8 ? sum8_dpp(ss) : sum16_dpp(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), eps);
+  if (live && mine) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_elem<OutT>(yr, 8 * l + e, v[e] * inv);
+  }
+}
+template <typename InT, typename OutT>
+static void l2norm_launch_short(const InT* x, int64_t so, int64_t si, int inner, OutT* y, int64_t yo, int64_t yi, int64_t rows, int D, float eps, hipStream_t s) {
+  if (D <= 64) hipLaunchKernelGGL((l2norm_rows_short_kernel<InT, OutT, 8>), dim3((unsigned)cdiv(rows, 32)), dim3(256), 0, s, x, so, si, inner, y, yo, yi, rows, D, eps);
+  else hipLaunchKernelGGL((l2norm_rows_short_kernel<InT, OutT, 16>), dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, s, x, so, si, inner, y, yo, yi, rows, D, eps);
+}
 template <typename InT>
 static void l2norm_launch_out(const InT* x, int64_t so, int64_t si, int inner, void* y, int y_kind, int64_t yo, int64_t yi, int64_t rows, int D,
                               float eps, dim3 grid, hipStream_t s) {
+  if (D <= 128 && D % 8 == 0 && rows >= 4096) {             // many short rows
+    if (y_kind == HK_F16X2) l2norm_launch_short<InT, h2_t>(x, so, si, inner, (h2_t*)y, yo, yi, rows, D, eps, s);
+    else if (y_kind == HK_F16) l2norm_launch_short<InT, f16_t>(x, so, si, inner, (f16_t*)y, yo, yi, rows, D, eps, s);
+    else if (y_kind == HK_BF16) l2norm_launch_short<InT, bf16_t>(x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps, s);
+    else l2norm_launch_short<InT, float>(x, so, si, inner, (float*)y, yo, yi, rows, D, eps, s);
+    return;
+  }
   if (y_kind == HK_F16X2) hipLaunchKernelGGL((l2norm_rows_kernel<InT, h2_t>), grid, dim3(256), 0, s, x, so, si, inner, (h2_t*)y, yo, yi, rows, D, eps);
   else if (y_kind == HK_F16) hipLaunchKernelGGL((l2norm_rows_kernel<InT, f16_t>), grid, dim3(256), 0, s, x, so, si, inner, (f16_t*)y, yo, yi, rows, D, eps);
   else if (y_kind == HK_BF16) hipLaunchKernelGGL((l2norm_rows_kernel<InT, bf16_t>), grid, dim3(256), 0, s, x, so, si, inner, (bf16_t*)y, yo, yi, rows, D, eps);
