@@ -56,6 +56,7 @@ SIGNATURES = {
     "sg_vit_workspace_bytes": (Z, [P, I, I, I, C.POINTER(ForwardOpts)]),
     "sg_vit_forward": (I, [P, C.POINTER(TileBatch), C.POINTER(ForwardOpts), P, P, P, Z, P]),
     "sg_cosine_logits": (I, [P, P, P, I, I, I, I, F, F, P, P]),
+    "sg_cosine_logits_two_plane": (I, [P, P, P, I, I, I, I, F, P, P]),
     "sg_stitch": (I, [P, P, I, I, I, I, I, I, I, I, I, I, P, P]),
     "sg_resize_bilinear": (I, [P, I, I, I, P, I, I, P]),
     "sg_postprocess": (I, [P, P, I, I, I, I, F, F, I, P, P, P]),

@@ -409,16 +409,6 @@ extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const flo
   SG_REQUIRE(tokens && text && logits, "sg_cosine_logits: null pointer");
   SG_REQUIRE(B > 0 && n > 0 && E > 0 && Q > 0 && B < 65536, "sg_cosine_logits: bad shape B=%d n=%d E=%d Q=%d", B, n, E, Q);
   SG_REQUIRE(cls || (global_debias_factor == 0.f && cls_token_lambda == 0.f), "sg_cosine_logits: cls required for debias / lambda");
-  if (global_debias_factor == 0.f && Q <= 16 && E % 32 == 0 && n >= 16384 && (((uintptr_t)logits) & 15) == 0) {   // per-pixel logits: the matrix-pipe form
-    const size_t ldsm = (size_t)2 * 16 * (E + 8) * 2 + (4 * 64 + 16) * sizeof(float);
-    if (ldsm <= 160 * 1024) {
-      if (ldsm > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sg::cosine_logits_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
-      hipLaunchKernelGGL(sg::cosine_logits_mfma_kernel, dim3((unsigned)cdiv(n, 4 * 64 * sg::CLM_ROUNDS), (unsigned)B), dim3(256), ldsm, as_stream(s), tokens, cls, text,
-                         n, E, Q, cls_token_lambda, logits);
-      SG_LAUNCH_CHECK();
-      return SG_OK;
-    }
-  }
   const size_t lds = ((size_t)Q * E + E + Q) * sizeof(float);
   SG_REQUIRE(lds <= 160 * 1024, "sg_cosine_logits: Q*E=%d exceeds LDS", Q * E);
   SG_REQUIRE(E <= 64 * CL_MAXV && E % 4 == 0, "sg_cosine_logits: E=%d must be a multiple of 4 and <= %d", E, 64 * CL_MAXV);
@@ -428,6 +418,24 @@ extern "C" int sg_cosine_logits(const float* tokens, const float* cls, const flo
   if (lds > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(n, CL_TPB), (unsigned)B), dim3(256), lds, as_stream(s), tokens, cls, text,
                      n, E, Q, global_debias_factor, cls_token_lambda, logits);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+// The per-pixel logits of the EXACT tower mode (SG_PREC_F16X2): the same contract as sg_cosine_logits without the global debias, on the f16 matrix
+// pipe with every operand as two f16 planes (f32-grade; like everything in that mode, magnitudes beyond +-131 008 saturate -- sg_cosine_logits
+// itself stays plain f32 arithmetic with no such bound).  Shapes the matrix-pipe form does not take (Q > 16, E % 32 != 0, small n) go to sg_cosine_logits.
+extern "C" int sg_cosine_logits_two_plane(const float* tokens, const float* cls, const float* text, int B, int n, int E, int Q,
+                                          float cls_token_lambda, float* logits, sg_stream s) {
+  SG_REQUIRE(tokens && text && logits, "sg_cosine_logits_two_plane: null pointer");
+  SG_REQUIRE(B > 0 && n > 0 && E > 0 && Q > 0 && B < 65536, "sg_cosine_logits_two_plane: bad shape B=%d n=%d E=%d Q=%d", B, n, E, Q);
+  SG_REQUIRE(cls || cls_token_lambda == 0.f, "sg_cosine_logits_two_plane: cls required for lambda");
+  const size_t ldsm = (size_t)2 * 16 * (E + 8) * 2 + (4 * 64 + 16) * sizeof(float);
+  if (!(Q <= 16 && E % 32 == 0 && n >= 4096 && (((uintptr_t)logits) & 15) == 0 && (((uintptr_t)tokens) & 15) == 0 && ldsm <= 160 * 1024))
+    return sg_cosine_logits(tokens, cls, text, B, n, E, Q, 0.f, cls_token_lambda, logits, s);
+  if (ldsm > 48 * 1024) SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sg::cosine_logits_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+  hipLaunchKernelGGL(sg::cosine_logits_mfma_kernel, dim3((unsigned)cdiv(n, 4 * 64 * sg::CLM_ROUNDS), (unsigned)B), dim3(256), ldsm, as_stream(s), tokens, cls, text,
+                     n, E, Q, cls_token_lambda, logits);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

@@ -242,8 +242,9 @@ def weak_token_replace(feats, attn_diag, gh: int, gw: int, top_k: int = 10):
 
 
 @on_tensor_device
-def cosine_logits(tokens, cls, text, global_debias_factor: float = 0.0, cls_token_lambda: float = 0.0):
-    """tokens [B,n,E], cls [B,E] or None, text [Q,E] -> logits [B,Q,n] (segmentor.py:309-336,374-386)."""
+def cosine_logits(tokens, cls, text, global_debias_factor: float = 0.0, cls_token_lambda: float = 0.0, two_plane: bool = False):
+    """tokens [B,n,E], cls [B,E] or None, text [Q,E] -> logits [B,Q,n] (segmentor.py:309-336,374-386).
+    ``two_plane`` (no global debias): the per-pixel form of the exact tower mode -- the product on the f16 matrix pipe, operands as two f16 planes."""
     lib = _lib.load()
     tokens, text = _f32(tokens), _f32(text)
     cls = None if cls is None else _f32(cls)
@@ -251,6 +252,10 @@ def cosine_logits(tokens, cls, text, global_debias_factor: float = 0.0, cls_toke
     B, n, E = tokens.shape
     Q = text.shape[0]
     out = torch.empty(B, Q, n, dtype=torch.float32, device=tokens.device)
+    if two_plane and float(global_debias_factor) == 0.0:
+        check(lib.sg_cosine_logits_two_plane(ptr(tokens), ptr(cls), ptr(text), B, n, E, Q, float(cls_token_lambda), ptr(out), stream_ptr()),
+              "sg_cosine_logits_two_plane")
+        return out
     check(lib.sg_cosine_logits(ptr(tokens), ptr(cls), ptr(text), B, n, E, Q, float(global_debias_factor), float(cls_token_lambda),
                                ptr(out), stream_ptr()), "sg_cosine_logits")
     return out

@@ -151,6 +151,6 @@ class HipJBU:
                                                  ptr(lg), wp, wn, stream_ptr(self.device)), "sg_jbu_logits")
                 else:
                     feats = self.upsample_tokens(tokens[i:i + c], guid, gh, gw)                      # [c, 256 n, C]
-                    lg = ops.cosine_logits(feats, None if cls is None else cls[i:i + c], text, 0.0, lam)
+                    lg = ops.cosine_logits(feats, None if cls is None else cls[i:i + c], text, 0.0, lam, two_plane=self.precision == _lib.PREC_F16X2)
                 outs.append(lg.reshape(c, Q, 16 * gh, 16 * gw))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]

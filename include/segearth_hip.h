@@ -161,6 +161,12 @@ int sg_vit_forward(sg_context* ctx, const sg_tile_batch* tiles, const sg_forward
  *   tokens [B,n,E], cls [B,E] (may be NULL when both factors are 0), text [Q,E] -> logits [B,Q,n]. */
 int sg_cosine_logits(const float* tokens, const float* cls, const float* text, int B, int n, int E, int Q,
                      float global_debias_factor, float cls_token_lambda, float* logits, sg_stream s);
+/* The per-pixel logits behind the upsampler (segmentor.py:374-379, no global debias: it ran before the upsampler) for the exact tower mode
+ * SG_PREC_F16X2: the [n, E] x [E, Q] product on the f16 matrix pipe with both operands as two f16 planes (f32-grade results, three MFMAs per
+ * product; magnitudes beyond +-131 008 saturate, as everywhere in that mode).  Same layouts as sg_cosine_logits; shapes it does not take
+ * (Q > 16, E % 32 != 0, n < 4096) are forwarded to sg_cosine_logits. */
+int sg_cosine_logits_two_plane(const float* tokens, const float* cls, const float* text, int B, int n, int E, int Q,
+                               float cls_token_lambda, float* logits, sg_stream s);
 
 /* sg_stitch replaces the bilinear upsample + un-pad + overlap-add + count-normalise of
  * segmentor.py:388-391,436-447 in a write-once form: canvas[q,y,x] = mean over covering tiles

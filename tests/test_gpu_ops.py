@@ -240,6 +240,23 @@ def test_cosine_logits(ops):
     assert (out.cpu() - (f @ text.T).permute(0, 2, 1)).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("B,n,E,Q,lam", [(2, 16384 + 37, 96, 7, -0.3), (1, 20000, 768, 16, 0.0), (3, 16384, 64, 1, 0.5), (1, 65536 + 2, 128, 13, 0.2)])
+def test_cosine_logits_per_pixel_form(ops, B, n, E, Q, lam):
+    """sg_cosine_logits_two_plane (the per-pixel logits of the exact tower mode) runs as a GEMM on the matrix pipe: f32 rows split into two f16 planes,
+    three MFMAs per product (head.hip: cosine_logits_mfma_kernel).  f32-grade against f64, ragged n (not a multiple of 4 / 64), Q below 16, cls term."""
+    tok, cls = rnd(B, n, E, seed=11) * torch.logspace(-2, 2, n).view(1, n, 1), rnd(B, E, seed=12)
+    text = torch.nn.functional.normalize(rnd(Q, E, seed=13), dim=-1)
+    f = tok.double()
+    ref = (f / f.norm(dim=-1, keepdim=True)) @ text.double().T
+    if lam:
+        c = cls.double()
+        ref = ref + ((c / c.norm(dim=-1, keepdim=True)) @ text.double().T).unsqueeze(1) * lam
+    out = ops.cosine_logits(tok.to(DEV), cls.to(DEV) if lam else None, text.to(DEV), 0.0, lam, two_plane=True)
+    err = (out.cpu().double() - ref.permute(0, 2, 1)).abs().max().item()
+    print(f"per-pixel cosine logits B={B} n={n} E={E} Q={Q}: max err {err:.2e}")
+    assert out.shape == (B, Q, n) and err < 2e-6
+
+
 @pytest.mark.parametrize("src,dst", [((7, 9), (21, 30)), ((14, 14), (224, 224)), ((37, 37), (518, 518)), ((10, 12), (10, 12)), ((16, 16), (9, 11))])
 def test_resize_bilinear(ops, src, dst):
     x = rnd(5, *src, seed=4)
