@@ -221,19 +221,22 @@ __global__ __launch_bounds__(256) void jbu_kernel_tiled_kernel(const float* __re
 // as NT tiles of ONE v_mfma_f32_16x16x32_f16 each (K = KEY_DIM = 32), parks S as [8 pixels][positions] f32 in LDS and then walks the pixels
 // with the taps on the lanes as before -- one ds_read_b32 per tap instead of eight ds_read_b128.  Same softmax / normalisation arithmetic,
 // same outputs (X f32 rows, X16 bf16 operand rows).
-template <int R>
+template <int R, bool EXACT = false>
 struct JkmCfg {
   static constexpr int D = 2 * R + 1, D2 = D * D, WT = AC_T + 2 * R, NWIN = WT * WT;
   static constexpr int NROWPOS = (D - 1) * WT + D + 7;                 // window positions (relative to the row's first) the taps of a pixel row touch
   static constexpr int NT = (NROWPOS + 15) / 16, SP = NT * 16, LDS_S = SP + 4;
-  static constexpr int KLD = KEY_DIM + 8;                               // f16 key row stride (80 bytes)
+  static constexpr int KLD = (EXACT ? 2 : 1) * KEY_DIM + 8;            // f16 key row stride (80 bytes; EXACT: [32 hi | 32 lo] + 8 = 144 bytes)
   static constexpr size_t LDS = (size_t)NWIN * KLD * 2 + (size_t)4 * 8 * LDS_S * 4;
 };
-template <int R>
+// EXACT (the upsampler under SG_PREC_F16X2): the keys as two f16 planes and three MFMAs per product (f32-grade scores), expf / true division as in
+// the parity kernel, outputs = the f32 rows plus the fixup GEMM's operand rows in TWO-PLANE f16 ([8 hi | 8 lo] groups, X16 then points to h2_t rows of
+// ldx16 elements) -- the separate pack pass of that mode is gone.
+template <int R, bool EXACT = false>
 __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __restrict__ proj, const float* __restrict__ gs, int H, int W,
                                                                  const float* __restrict__ range_temp, const float* __restrict__ sigma,
                                                                  float* __restrict__ X, bf16_t* __restrict__ X16, int ldx16, int half_only) {
-  using J = JkmCfg<R>;
+  using J = JkmCfg<R, EXACT>;
   constexpr int D = J::D, D2 = J::D2, LDX = D2 + 3, WT = J::WT, NWIN = J::NWIN, NT = J::NT, LDS_S = J::LDS_S, KLD = J::KLD;
   static_assert(KEY_DIM == 32, "one MFMA k-step per product");
   extern __shared__ __attribute__((aligned(16))) char jkm_sm[];
@@ -258,8 +261,14 @@ __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + tid + u * 256;
-      if (i < NWIN * (KEY_DIM / 4))
-        *reinterpret_cast<uint2*>(win + (i / (KEY_DIM / 4)) * KLD + 4 * (i % (KEY_DIM / 4))) = make_uint2(pack_h2(pv[u].x, pv[u].y), pack_h2(pv[u].z, pv[u].w));
+      if (i < NWIN * (KEY_DIM / 4)) {
+        uint16_t* wr = win + (i / (KEY_DIM / 4)) * KLD + 4 * (i % (KEY_DIM / 4));
+        if constexpr (EXACT) {
+          uint2 hv, lv;
+          split_h2(pv[u].x, pv[u].y, hv.x, lv.x); split_h2(pv[u].z, pv[u].w, hv.y, lv.y);
+          *reinterpret_cast<uint2*>(wr) = hv; *reinterpret_cast<uint2*>(wr + KEY_DIM) = lv;
+        } else *reinterpret_cast<uint2*>(wr) = make_uint2(pack_h2(pv[u].x, pv[u].y), pack_h2(pv[u].z, pv[u].w));
+      }
     }
   }
   __syncthreads();
@@ -288,7 +297,13 @@ __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __
         int pos = py * WT + nt * 16 + li;
         pos = pos < NWIN ? pos : NWIN - 1;
         const bf16x8 pfrag = *reinterpret_cast<const bf16x8*>(win + pos * KLD + 8 * lg);                             // first port: row = window position
-        const f32x4 acc = mfma_16x16x32<true>(pfrag, cfrag, (f32x4){0.f, 0.f, 0.f, 0.f});   // lane: pixel li, positions nt*16 + 4 lg .. + 3
+        f32x4 acc = mfma_16x16x32<true>(pfrag, cfrag, (f32x4){0.f, 0.f, 0.f, 0.f});   // lane: pixel li, positions nt*16 + 4 lg .. + 3
+        if constexpr (EXACT) {
+          const bf16x8 pl = *reinterpret_cast<const bf16x8*>(win + pos * KLD + KEY_DIM + 8 * lg);
+          const bf16x8 cl = *reinterpret_cast<const bf16x8*>(win + ((py + R) * WT + (li & 7) + R) * KLD + KEY_DIM + 8 * lg);
+          acc = mfma_16x16x32<true>(pl, cfrag, acc);
+          acc = mfma_16x16x32<true>(pfrag, cl, acc);
+        }
         if (li < 8) *reinterpret_cast<float4*>(myS + li * LDS_S + nt * 16 + 4 * lg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       }
     }
@@ -311,14 +326,17 @@ __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __
       float ex[2][2], s1[2], s2v[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        ex[e][0] = __builtin_amdgcn_exp2f((val[e][0] - mx[e]) * 1.4426950408889634f);
-        ex[e][1] = __builtin_amdgcn_exp2f((val[e][1] - mx[e]) * 1.4426950408889634f);
+        if constexpr (EXACT) { ex[e][0] = expf(val[e][0] - mx[e]); ex[e][1] = expf(val[e][1] - mx[e]); }      // exp(-inf) = 0 for the unused lanes
+        else {
+          ex[e][0] = __builtin_amdgcn_exp2f((val[e][0] - mx[e]) * 1.4426950408889634f);
+          ex[e][1] = __builtin_amdgcn_exp2f((val[e][1] - mx[e]) * 1.4426950408889634f);
+        }
         s1[e] = ex[e][0] + ex[e][1];
       }
       s1[0] = wave_sum_dpp(s1[0]); s1[1] = wave_sum_dpp(s1[1]);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float inv = __builtin_amdgcn_rcpf(s1[e]);
+        const float inv = EXACT ? 1.0f / s1[e] : __builtin_amdgcn_rcpf(s1[e]);
         ex[e][0] = ex[e][0] * inv * sp[0]; ex[e][1] = ex[e][1] * inv * sp[1];
         s2v[e] = ex[e][0] + ex[e][1];
       }
@@ -326,8 +344,10 @@ __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         if (!live[e]) continue;
-        const float rn = __builtin_amdgcn_rcpf(fmaxf(s2v[e], 1e-7f));
-        const float k0 = ex[e][0] * rn, k1 = ex[e][1] * rn;
+        const float nrm = fmaxf(s2v[e], 1e-7f);
+        float k0, k1;
+        if constexpr (EXACT) { k0 = ex[e][0] / nrm; k1 = ex[e][1] / nrm; }
+        else { const float rn = __builtin_amdgcn_rcpf(nrm); k0 = ex[e][0] * rn; k1 = ex[e][1] * rn; }
         const int64_t pix = pixi[e];
         // [taps | guidance | zero padding]: the 2-byte A operand of the fixup GEMM.  half_only (the all-f16 fixup chain of the low-res path): f16
         // rows that also serve as that chain's residual, and no f32 rows at all (752 -> 256 bytes written per pixel)
@@ -335,7 +355,15 @@ __global__ __launch_bounds__(256, 2) void jbu_kernel_mfma_kernel(const float* __
         const int t2 = lane + 64;
         const float v1 = t2 < D2 ? k1 : (t2 < D2 + 3 ? gs[pix * 3 + (t2 - D2)] : 0.f);
         bf16_t* x16 = X16 + pix * ldx16;
-        if (half_only) {
+        if constexpr (EXACT) {                                            // f32 rows (the fixup residual) + two-plane operand rows
+          float* xr = X + pix * LDX;
+          if (lane < D2) xr[lane] = k0;
+          if (lane + 64 < D2) xr[lane + 64] = k1;
+          if (lane < 3) xr[D2 + lane] = gs[pix * 3 + lane];
+          h2_t* x2r = reinterpret_cast<h2_t*>(X16) + pix * ldx16;
+          if (lane < ldx16) st_elem<h2_t>(x2r, lane, v0);
+          if (t2 < ldx16) st_elem<h2_t>(x2r, t2, v1);
+        } else if (half_only) {
           if (lane < ldx16) x16[lane] = f2h(v0).bits;
           if (t2 < ldx16) x16[t2] = f2h(v1).bits;
         } else {
@@ -1279,7 +1307,17 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
       using JK = void (*)(const float*, const float*, int, int, int, const float*, const float*, float*, bf16_t*, int);
       const JK jk = fast ? (r == 5 ? jbu_kernel_tiled_kernel<5, true> : r == 3 ? jbu_kernel_tiled_kernel<3, true> : jbu_kernel_tiled_kernel<0, true>)
                          : jbu_kernel_tiled_kernel<0, false>;
-      if (fast && (r == 5 || r == 3)) {                     // key dot products on the matrix pipe
+      if (x2 && (r == 5 || r == 3)) {                       // exact mode: two-plane keys, exact arithmetic, two-plane operand rows written directly
+        const dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
+        constexpr size_t lds5 = JkmCfg<5, true>::LDS, lds3 = JkmCfg<3, true>::LDS;
+        if (r == 5) {
+          SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_mfma_kernel<5, true>), lds5));
+          hipLaunchKernelGGL((jbu_kernel_mfma_kernel<5, true>), grid, dim3(256), lds5, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1, 0);
+        } else {
+          SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_mfma_kernel<3, true>), lds3));
+          hipLaunchKernelGGL((jbu_kernel_mfma_kernel<3, true>), grid, dim3(256), lds3, s, p.proj, p.gs, oh, ow, S.range_temp, S.sigma, p.X, p.X16, KP1, 0);
+        }
+      } else if (fast && (r == 5 || r == 3)) {               // key dot products on the matrix pipe
         const dim3 grid((unsigned)(cdiv(oh, AC_T) * cdiv(ow, AC_T)), (unsigned)B);
         if (r == 5) {
           SG_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(jbu_kernel_mfma_kernel<5>), JkmCfg<5>::LDS));
@@ -1308,7 +1346,7 @@ static int jbu_stages(sg_jbu* j, const float* source, const float* guidance, int
       else { q.residual = p.X; q.ldr = d2 + 3; q.c_is_bf16 = 0; }
       SG_TRY(gemm_bf16(q, s));
     } else if (x2) {  // the same two linears on the two-plane GEMM: X rows packed to [KP1] two-plane, GELU output two-plane, Kf f32 rows of NP
-      SG_TRY(pack_rows(p.X, pixels, d2 + 3, d2 + 3, p.X16, KP1, HK_F16X2, s));
+      if (!(r == 5 || r == 3)) SG_TRY(pack_rows(p.X, pixels, d2 + 3, d2 + 3, p.X16, KP1, HK_F16X2, s));   // (r = 3 / 5: the range kernel wrote the two-plane rows itself)
       GemmBf16Args g{};
       g.A = p.X16; g.lda = KP1; g.W = (const bf16_t*)S.fx0_wh2; g.ldw = KP1; g.bias = S.fx0_bp; g.C = p.H116; g.ldc = NP; g.c_is_bf16 = 1;
       g.M = (int)pixels; g.N = NP; g.K = KP1; g.batch = 1; g.act = ACT_GELU; g.alpha = 1.f; g.h2 = 1;
