@@ -4,8 +4,10 @@
 Used while tuning: a kernel that spills (scratch > 0) or drops a wave per SIMD shows up here before it shows up in a timing."""
 import os, re, subprocess, sys
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "clip_decontamination_amd", "csrc")
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from clip_decontamination_amd.build import EXTRA_FLAGS       # the per-unit flags of the real build (e.g. -fno-slp-vectorize)
 src = sys.argv[1]
-cmd = ["hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-result", *sys.argv[2:], "-c", src, "-o", "/dev/null",
+cmd = ["hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-result", *EXTRA_FLAGS.get(src, []), *sys.argv[2:], "-c", src, "-o", "/dev/null",
        "-Rpass-analysis=kernel-resource-usage"]
 log = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True).stderr
 rows, cur = [], {}
